@@ -1,0 +1,630 @@
+// C-ABI layer of libcellector_hip.so (include/cellector_ffi.h): argument checking, state machine,
+// host<->device copies and the host-side scalar arithmetic of the scoring loop (threshold, priors).
+// All matrix work is in the HIP kernels (kernels_*.hip); there is no CPU fallback.
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+#include "ctx.h"
+
+cellector_status ctx_fail(const cellector_ctx *c, cellector_status s, const char *fmt, ...)
+{
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf;
+    return s;
+}
+
+// ---- timing -----------------------------------------------------------------------------------------
+void timer_begin(cellector_ctx *c, int which)
+{
+    if (!c->timing) return;
+    hipEvent_t a, b;
+    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+    c->timers[which].start.push_back(a);
+    c->timers[which].stop.push_back(b);
+    (void)hipEventRecord(a, c->stream);
+}
+void timer_end(cellector_ctx *c, int which)
+{
+    if (!c->timing) return;
+    KernelTimer &t = c->timers[which];
+    if (t.stop.empty()) return;
+    (void)hipEventRecord(t.stop.back(), c->stream);
+}
+void timer_collect(cellector_ctx *c)
+{
+    for (int k = 0; k < CELLECTOR_K_COUNT; k++) {
+        KernelTimer &t = c->timers[k];
+        for (size_t i = 0; i < t.start.size(); i++) {
+            float ms = 0.f;
+            if (hipEventSynchronize(t.stop[i]) == hipSuccess &&
+                hipEventElapsedTime(&ms, t.start[i], t.stop[i]) == hipSuccess) {
+                t.total_ms += ms;
+                t.launches++;
+            }
+            (void)hipEventDestroy(t.start[i]);
+            (void)hipEventDestroy(t.stop[i]);
+        }
+        t.start.clear();
+        t.stop.clear();
+    }
+}
+
+static void free_matrix(cellector_ctx *c)
+{
+    dev_free(c->coo_locus); dev_free(c->coo_cell); dev_free(c->coo_alt); dev_free(c->coo_ref);
+    dev_free(c->csr_ptr); dev_free(c->csr_ent); dev_free(c->csc_ptr); dev_free(c->csc_ent);
+    dev_free(c->locus_ids); dev_free(c->s_alt); dev_free(c->s_ref); dev_free(c->n_ent); dev_free(c->to_used);
+    dev_free(c->ab); dev_free(c->ab6); dev_free(c->mask); dev_free(c->mask_next);
+    dev_free(c->flags); dev_free(c->flags_new); dev_free(c->ll); dev_free(c->ell); dev_free(c->nloci);
+    dev_free(c->post);
+    if (c->own_pass1) dev_free(c->x_pass1);
+    if (c->own_norm) dev_free(c->x_norm);
+    if (c->own_locus) dev_free(c->x_locus);
+    c->x_pass1 = c->x_norm = c->x_locus = nullptr;
+    c->own_pass1 = c->own_norm = c->own_locus = true;
+    c->n_pass1 = c->n_norm = c->n_locus = 0;
+    c->coo_n = 0; c->L = c->nnz = c->nloc = 0;
+    c->state = cellector_ctx::ST_EMPTY;
+    c->em_phase = 0; c->iteration = 0; c->have_iter = false; c->n_excluded_global = 0;
+}
+
+#define REQUIRE(c, cond, msg)                                        \
+    do {                                                             \
+        if (!(cond)) return ctx_fail((c), CELLECTOR_EINVAL, "%s", msg); \
+    } while (0)
+#define SETDEV(c) HIPCHK((c), hipSetDevice((c)->device))
+
+extern "C" {
+
+const char *cellector_version(void) { return "cellector_amd 0.1 (gfx950)"; }
+
+cellector_status cellector_create(cellector_ctx **out, int device_id)
+{
+    if (!out) return CELLECTOR_EINVAL;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device_id < 0 || device_id >= n) return CELLECTOR_EDEVICE;
+    if (hipSetDevice(device_id) != hipSuccess) return CELLECTOR_EDEVICE;
+    cellector_ctx *c = new (std::nothrow) cellector_ctx();
+    if (!c) return CELLECTOR_ENOMEM;
+    c->device = device_id;
+    // ln(FCACHE[x]), x = 0..170: statrs' factorial cache, logs taken with the host libm like the reference
+    double lf[LF_TABLE_N], f = 1.0;
+    lf[0] = std::log(1.0);
+    for (int i = 1; i < LF_TABLE_N; i++) {
+        f *= (double)i;
+        lf[i] = std::log(f);
+    }
+    bool ok = hipMalloc((void **)&c->lf, sizeof lf) == hipSuccess &&
+              hipMemcpy(c->lf, lf, sizeof lf, hipMemcpyHostToDevice) == hipSuccess &&
+              hipMalloc((void **)&c->d_counters, 8 * sizeof(uint32_t)) == hipSuccess &&
+              hipMalloc((void **)&c->sel_hist, SEL_T * 256 * sizeof(uint32_t)) == hipSuccess &&
+              hipMalloc((void **)&c->sel_state, 4 * SEL_T * sizeof(uint64_t)) == hipSuccess &&
+              hipHostMalloc((void **)&c->h_sel, 8 * sizeof(uint64_t)) == hipSuccess;
+    if (!ok) {
+        cellector_destroy(c);
+        return CELLECTOR_EDEVICE;
+    }
+    *out = c;
+    return CELLECTOR_OK;
+}
+
+void cellector_destroy(cellector_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    timer_collect(c);
+    free_matrix(c);
+    dev_free(c->lf); dev_free(c->d_counters); dev_free(c->sel_hist); dev_free(c->sel_state);
+    if (c->h_sel) (void)hipHostFree(c->h_sel);
+    delete c;
+}
+
+const char *cellector_last_error(const cellector_ctx *c) { return c ? c->err.c_str() : "null ctx"; }
+
+cellector_status cellector_set_stream(cellector_ctx *c, void *s)
+{
+    if (!c) return CELLECTOR_EINVAL;
+    c->stream = (hipStream_t)s;
+    return CELLECTOR_OK;
+}
+
+cellector_status cellector_set_option(cellector_ctx *c, const char *key, int64_t v)
+{
+    if (!c || !key) return CELLECTOR_EINVAL;
+    if (!strcmp(key, "compute_expected")) c->compute_expected = v != 0;
+    else if (!strcmp(key, "timing")) c->timing = v != 0;
+    else if (!strcmp(key, "keep_coo")) c->keep_coo = v != 0;
+    else return ctx_fail(c, CELLECTOR_EINVAL, "unknown option '%s'", key);
+    return CELLECTOR_OK;
+}
+
+cellector_status cellector_set_shard(cellector_ctx *c, uint64_t b, uint64_t e)
+{
+    if (!c) return CELLECTOR_EINVAL;
+    REQUIRE(c, c->state == cellector_ctx::ST_EMPTY, "set_shard must precede ingest");
+    REQUIRE(c, b <= e, "empty or inverted shard range");
+    c->cell_begin = b;
+    c->cell_end = e;
+    return CELLECTOR_OK;
+}
+
+// ---- ingest -------------------------------------------------------------------------------------------
+static cellector_status begin_ingest(cellector_ctx *c, uint64_t total_loci, uint64_t total_cells)
+{
+    SETDEV(c);
+    {
+        // keep a caller-bound PASS1 buffer across the reset
+        double *bound = c->own_pass1 ? nullptr : c->x_pass1;
+        uint64_t nb = c->n_pass1;
+        uint64_t cb = c->cell_begin, ce = c->cell_end;
+        free_matrix(c);
+        c->cell_begin = cb; c->cell_end = ce;
+        if (bound) { c->x_pass1 = bound; c->n_pass1 = nb; c->own_pass1 = false; }
+    }
+    REQUIRE(c, total_loci <= 0xffffffffull && total_cells <= 0xffffffffull, "dims exceed 32-bit indices");
+    c->total_loci = total_loci;
+    c->total_cells = total_cells;
+    if (c->cell_end > total_cells) c->cell_end = total_cells;
+    if (c->cell_begin > c->cell_end) c->cell_begin = c->cell_end;
+    c->nloc = c->cell_end - c->cell_begin;
+    const uint64_t need = (uint64_t)P1_PLANES * total_loci;
+    if (c->x_pass1) {
+        REQUIRE(c, c->n_pass1 >= need, "bound PASS1 exchange buffer too small");
+    } else {
+        CHK(dev_alloc(c, &c->x_pass1, need));
+        c->own_pass1 = true;
+    }
+    c->n_pass1 = need;
+    return CELLECTOR_OK;
+}
+
+cellector_status cellector_ingest_coo(cellector_ctx *c, uint64_t total_loci, uint64_t total_cells, uint64_t nnz,
+                                      const uint32_t *locus0, const uint32_t *cell0, const uint32_t *alt,
+                                      const uint32_t *ref)
+{
+    if (!c) return CELLECTOR_EINVAL;
+    REQUIRE(c, nnz == 0 || (locus0 && cell0 && alt && ref), "null COO array");
+    CHK(begin_ingest(c, total_loci, total_cells));
+    CHK(ingest_stage_host_coo(c, nnz, locus0, cell0, alt, ref));
+    CHK(ingest_pass1(c));
+    c->state = cellector_ctx::ST_STAGED;
+    return CELLECTOR_OK;
+}
+
+cellector_status cellector_ingest_mtx(cellector_ctx *c, const char *alt_path, const char *ref_path)
+{
+    if (!c) return CELLECTOR_EINVAL;
+    REQUIRE(c, alt_path && ref_path, "null path");
+    HostCoo coo;
+    CHK(read_mtx_pair(c, alt_path, ref_path, &coo));
+    return cellector_ingest_coo(c, coo.total_loci, coo.total_cells, coo.locus.size(), coo.locus.data(),
+                                coo.cell.data(), coo.alt.data(), coo.ref.data());
+}
+
+cellector_status cellector_ingest_synthetic(cellector_ctx *c, uint64_t total_loci, uint64_t total_cells,
+                                            double density, uint64_t seed, double minority_fraction,
+                                            double doublet_fraction)
+{
+    if (!c) return CELLECTOR_EINVAL;
+    CHK(begin_ingest(c, total_loci, total_cells));
+    CHK(synth_generate(c, density, seed, minority_fraction, doublet_fraction));
+    CHK(ingest_pass1(c));
+    c->state = cellector_ctx::ST_STAGED;
+    return CELLECTOR_OK;
+}
+
+cellector_status cellector_ingest_finish(cellector_ctx *c, uint64_t min_alt, uint64_t min_ref)
+{
+    if (!c) return CELLECTOR_EINVAL;
+    REQUIRE(c, c->state == cellector_ctx::ST_STAGED, "ingest_finish without a staged matrix");
+    SETDEV(c);
+    CHK(ingest_build(c, min_alt, min_ref));
+    const uint64_t L = c->L, n = c->nloc;
+    CHK(dev_alloc(c, &c->ab, L)); CHK(dev_alloc(c, &c->ab6, 8 * L));
+    CHK(dev_alloc(c, &c->mask, L)); CHK(dev_alloc(c, &c->mask_next, L));
+    CHK(dev_alloc(c, &c->flags, n)); CHK(dev_alloc(c, &c->flags_new, n));
+    CHK(dev_alloc(c, &c->ll, n)); CHK(dev_alloc(c, &c->ell, n)); CHK(dev_alloc(c, &c->nloci, n));
+    CHK(dev_alloc(c, &c->post, 4 * n));
+    HIPCHK(c, hipMemsetAsync(c->mask, 1, L ? L : 1, c->stream));  // load_data.rs:176-179: all loci used
+    HIPCHK(c, hipMemsetAsync(c->mask_next, 1, L ? L : 1, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->flags, 0, n ? n : 1, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->flags_new, 0, n ? n : 1, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->ll, 0, (n ? n : 1) * 8, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->ell, 0, (n ? n : 1) * 8, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->nloci, 0, (n ? n : 1) * 8, c->stream));
+    const uint64_t need_norm = c->total_cells, need_locus = (uint64_t)LB_PLANES * L + LC_COUNTERS;
+    if (c->x_norm) REQUIRE(c, c->n_norm >= need_norm, "bound NORM exchange buffer too small");
+    else { CHK(dev_alloc(c, &c->x_norm, need_norm)); c->own_norm = true; }
+    if (c->x_locus) REQUIRE(c, c->n_locus >= need_locus, "bound LOCUS exchange buffer too small");
+    else { CHK(dev_alloc(c, &c->x_locus, need_locus)); c->own_locus = true; }
+    c->n_norm = need_norm;
+    c->n_locus = need_locus;
+    HIPCHK(c, hipMemsetAsync(c->x_norm, 0, (need_norm ? need_norm : 1) * 8, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->x_locus, 0, need_locus * 8, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->state = cellector_ctx::ST_READY;
+    c->em_phase = 0; c->iteration = 0; c->have_iter = false; c->n_excluded_global = 0;
+    return CELLECTOR_OK;
+}
+
+cellector_status cellector_load_mtx(cellector_ctx *c, const char *a, const char *r, uint64_t min_alt, uint64_t min_ref)
+{
+    CHK(cellector_ingest_mtx(c, a, r));
+    return cellector_ingest_finish(c, min_alt, min_ref);
+}
+
+cellector_status cellector_load_coo(cellector_ctx *c, uint64_t tl, uint64_t tc, uint64_t nnz, const uint32_t *l,
+                                    const uint32_t *ce, const uint32_t *a, const uint32_t *r, uint64_t min_alt,
+                                    uint64_t min_ref)
+{
+    CHK(cellector_ingest_coo(c, tl, tc, nnz, l, ce, a, r));
+    return cellector_ingest_finish(c, min_alt, min_ref);
+}
+
+// ---- accessors ----------------------------------------------------------------------------------------
+cellector_status cellector_dims(const cellector_ctx *c, cellector_dims_t *o)
+{
+    if (!c || !o) return CELLECTOR_EINVAL;
+    o->total_cells = c->total_cells; o->total_loci = c->total_loci; o->loci_used = c->L;
+    o->cell_begin = c->cell_begin; o->cell_end = c->cell_end; o->nnz_used = c->nnz;
+    return CELLECTOR_OK;
+}
+
+static cellector_status d2h(const cellector_ctx *c, void *dst, const void *src, size_t bytes)
+{
+    if (!bytes) return CELLECTOR_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return CELLECTOR_OK;
+}
+#define READY(c) REQUIRE(c, (c) && (c)->state == cellector_ctx::ST_READY, "no matrix loaded")
+
+cellector_status cellector_locus_ids(const cellector_ctx *c, uint64_t *out)
+{
+    if (!c) return CELLECTOR_EINVAL;
+    READY(c);
+    return d2h(c, out, c->locus_ids, c->L * 8);
+}
+
+cellector_status cellector_locus_counts(const cellector_ctx *c, double *out)
+{
+    if (!c) return CELLECTOR_EINVAL;
+    READY(c);
+    std::vector<double> a(c->L), r(c->L);
+    CHK(d2h(c, a.data(), c->s_alt, c->L * 8));
+    CHK(d2h(c, r.data(), c->s_ref, c->L * 8));
+    for (uint64_t l = 0; l < c->L; l++) { out[2 * l] = r[l]; out[2 * l + 1] = a[l]; }
+    return CELLECTOR_OK;
+}
+
+cellector_status cellector_entries_per_cell(const cellector_ctx *c, uint32_t *out)
+{
+    if (!c) return CELLECTOR_EINVAL;
+    READY(c);
+    std::vector<uint64_t> p(c->nloc + 1);
+    CHK(d2h(c, p.data(), c->csr_ptr, (c->nloc + 1) * 8));
+    for (uint64_t i = 0; i < c->nloc; i++) out[i] = (uint32_t)(p[i + 1] - p[i]);
+    return CELLECTOR_OK;
+}
+
+cellector_status cellector_csr_rows(const cellector_ctx *c, uint64_t rb, uint64_t re, uint64_t *row_ptr,
+                                    uint64_t *entries, uint64_t capacity)
+{
+    if (!c) return CELLECTOR_EINVAL;
+    READY(c);
+    REQUIRE(c, rb <= re && re <= c->nloc && row_ptr, "bad row range");
+    CHK(d2h(c, row_ptr, c->csr_ptr + rb, (re - rb + 1) * 8));
+    const uint64_t base = row_ptr[0], cnt = row_ptr[re - rb] - base;
+    for (uint64_t i = 0; i <= re - rb; i++) row_ptr[i] -= base;
+    if (entries) {
+        REQUIRE(c, capacity >= cnt, "entries capacity too small");
+        CHK(d2h(c, entries, c->csr_ent + base, cnt * 8));
+    }
+    return CELLECTOR_OK;
+}
+
+// ---- exchange buffers ---------------------------------------------------------------------------------
+cellector_status cellector_exchange_buffer(cellector_ctx *c, cellector_xchg which, void **dev_ptr, uint64_t *n)
+{
+    if (!c) return CELLECTOR_EINVAL;
+    double *p = nullptr;
+    uint64_t cnt = 0;
+    switch (which) {
+    case CELLECTOR_XCHG_PASS1: p = c->x_pass1; cnt = c->n_pass1; break;
+    case CELLECTOR_XCHG_NORM:
+        p = c->x_norm; cnt = c->state == cellector_ctx::ST_READY ? c->total_cells : c->n_norm; break;
+    case CELLECTOR_XCHG_LOCUS:
+        p = c->x_locus;
+        cnt = c->state == cellector_ctx::ST_READY ? (uint64_t)LB_PLANES * c->L + LC_COUNTERS : c->n_locus; break;
+    default: return ctx_fail(c, CELLECTOR_EINVAL, "unknown exchange buffer");
+    }
+    if (dev_ptr) *dev_ptr = p;
+    if (n) *n = cnt;
+    return CELLECTOR_OK;
+}
+
+cellector_status cellector_bind_exchange_buffer(cellector_ctx *c, cellector_xchg which, void *dev_ptr, uint64_t n)
+{
+    if (!c || !dev_ptr) return CELLECTOR_EINVAL;
+    double *p = (double *)dev_ptr;
+    switch (which) {
+    case CELLECTOR_XCHG_PASS1:
+        REQUIRE(c, c->state == cellector_ctx::ST_EMPTY, "bind PASS1 before ingest");
+        if (c->own_pass1) dev_free(c->x_pass1);
+        c->x_pass1 = p; c->n_pass1 = n; c->own_pass1 = false;
+        break;
+    case CELLECTOR_XCHG_NORM:
+        REQUIRE(c, c->state != cellector_ctx::ST_READY || n >= c->total_cells, "NORM buffer too small");
+        if (c->own_norm) dev_free(c->x_norm);
+        c->x_norm = p; c->n_norm = n; c->own_norm = false;
+        break;
+    case CELLECTOR_XCHG_LOCUS:
+        REQUIRE(c, c->state != cellector_ctx::ST_READY || n >= (uint64_t)LB_PLANES * c->L + LC_COUNTERS,
+                "LOCUS buffer too small");
+        if (c->state == cellector_ctx::ST_READY) {
+            // carry the current tallies over (they seed the next alpha/beta update)
+            HIPCHK(c, hipMemcpyAsync(p, c->x_locus, ((uint64_t)LB_PLANES * c->L + LC_COUNTERS) * 8,
+                                     hipMemcpyDeviceToDevice, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+        }
+        if (c->own_locus) dev_free(c->x_locus);
+        c->x_locus = p; c->n_locus = n; c->own_locus = false;
+        break;
+    default: return ctx_fail(c, CELLECTOR_EINVAL, "unknown exchange buffer");
+    }
+    return CELLECTOR_OK;
+}
+
+// ---- EM iteration -------------------------------------------------------------------------------------
+cellector_status cellector_em_begin(cellector_ctx *c)
+{
+    if (!c) return CELLECTOR_EINVAL;
+    READY(c);
+    REQUIRE(c, c->em_phase == 0, "em_begin: previous iteration not finished");
+    SETDEV(c);
+    CHK(launch_alpha_beta(c));
+    if (c->nloc != c->total_cells)  // other shards' slices must be zero before the sum-exchange
+        HIPCHK(c, hipMemsetAsync(c->x_norm, 0, c->total_cells * 8, c->stream));
+    CHK(launch_cell_ll(c, c->ab, c->x_norm + c->cell_begin));
+    c->em_phase = 1;
+    return CELLECTOR_OK;
+}
+
+cellector_status cellector_em_threshold(cellector_ctx *c, double iqr_multiple)
+{
+    if (!c) return CELLECTOR_EINVAL;
+    READY(c);
+    REQUIRE(c, c->em_phase == 1, "em_threshold without em_begin");
+    SETDEV(c);
+    const uint64_t n = c->total_cells;
+    REQUIRE(c, n > 0, "no cells");
+    // statrs Data::median / quantile: ranks of the order statistics needed
+    const uint64_t k = n / 2;
+    const double h1 = ((double)n + 1.0 / 3.0) * 0.25 + 1.0 / 3.0, h3 = ((double)n + 1.0 / 3.0) * 0.75 + 1.0 / 3.0;
+    const int64_t hf1 = (int64_t)h1, hf3 = (int64_t)h3;
+    auto clampr = [n](int64_t r) -> uint64_t { return r < 0 ? 0 : ((uint64_t)r >= n ? n - 1 : (uint64_t)r); };
+    uint64_t ranks[SEL_T] = {k ? k - 1 : 0, k, clampr(hf1 - 1), clampr(hf1), clampr(hf3 - 1), clampr(hf3)};
+    double v[SEL_T];
+    CHK(select_ranks(c, c->x_norm, n, ranks, v));
+    const double median = (n % 2 != 0) ? v[1] : (v[0] + v[1]) / 2.0;
+    auto quant = [&](double h, int64_t hf, double a, double b, double vmin, double vmax) {
+        if (hf <= 0) return vmin;
+        if (hf >= (int64_t)n) return vmax;
+        return a + (h - (double)hf) * (b - a);
+    };
+    // hf <= 0 / hf >= n only for n <= 2; the clamped ranks then already are min / max
+    const double q1 = quant(h1, hf1, v[2], v[3], v[3], v[2]);
+    const double q3 = quant(h3, hf3, v[4], v[5], v[5], v[4]);
+    const double iqr = q3 - q1;
+    const double thr = q1 - iqr_multiple * iqr;  // main.rs:328-329
+    c->last_median = median; c->last_iqr = iqr; c->last_thr = thr;
+    HIPCHK(c, hipMemsetAsync(c->x_locus + (uint64_t)LB_PLANES * c->L, 0, LC_COUNTERS * 8, c->stream));
+    CHK(launch_flag(c, thr));
+    CHK(launch_locus_stats(c));
+    c->em_phase = 2;
+    return CELLECTOR_OK;
+}
+
+cellector_status cellector_em_finish(cellector_ctx *c, cellector_iter_summary *out)
+{
+    if (!c) return CELLECTOR_EINVAL;
+    READY(c);
+    REQUIRE(c, c->em_phase == 2, "em_finish without em_threshold");
+    SETDEV(c);
+    HIPCHK(c, hipMemsetAsync(c->d_counters, 0, 8 * sizeof(uint32_t), c->stream));
+    CHK(launch_locus_filter(c));
+    double cnt[LC_COUNTERS];
+    uint32_t dc[8];
+    HIPCHK(c, hipMemcpyAsync(cnt, c->x_locus + (uint64_t)LB_PLANES * c->L, sizeof cnt, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(dc, c->d_counters, sizeof dc, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    std::swap(c->flags, c->flags_new);   // excluded_cells <- new_excluded (main.rs:43)
+    std::swap(c->mask, c->mask_next);    // loci_used for the next iteration; mask_next keeps this iteration's
+    c->n_excluded_global = (uint64_t)cnt[LC_N_EXCLUDED];
+    c->iteration++;
+    c->have_iter = true;
+    c->em_phase = 0;
+    if (c->timing) timer_collect(c);
+    if (out) {
+        out->n_new_excluded = (uint64_t)cnt[LC_N_NEW];
+        out->n_rescued = (uint64_t)cnt[LC_N_RESCUED];
+        out->n_excluded = c->n_excluded_global;
+        out->any_change = (out->n_new_excluded > 0 || out->n_rescued > 0) ? 1 : 0;  // main.rs:335
+        out->n_loci_filtered = dc[0];
+        out->median = c->last_median; out->iqr = c->last_iqr; out->threshold = c->last_thr;
+    }
+    return CELLECTOR_OK;
+}
+
+cellector_status cellector_em_iteration(cellector_ctx *c, double iqr_multiple, cellector_iter_summary *out)
+{
+    CHK(cellector_em_begin(c));
+    CHK(cellector_em_threshold(c, iqr_multiple));
+    return cellector_em_finish(c, out);
+}
+
+cellector_status cellector_iter_cell_outputs(const cellector_ctx *c, double *ll, double *ell, double *nl, double *norm)
+{
+    if (!c) return CELLECTOR_EINVAL;
+    READY(c);
+    const size_t b = c->nloc * 8;
+    if (ll) CHK(d2h(c, ll, c->ll, b));
+    if (ell) CHK(d2h(c, ell, c->ell, b));
+    if (nl) CHK(d2h(c, nl, c->nloci, b));
+    if (norm) CHK(d2h(c, norm, c->x_norm + c->cell_begin, b));
+    return CELLECTOR_OK;
+}
+
+cellector_status cellector_iter_locus_outputs(const cellector_ctx *c, double *cmin, double *cmaj, uint64_t *nmin,
+                                              uint64_t *nmaj, uint64_t *amin, uint64_t *rmin, uint64_t *amaj,
+                                              uint64_t *rmaj)
+{
+    if (!c) return CELLECTOR_EINVAL;
+    READY(c);
+    REQUIRE(c, c->have_iter && c->em_phase == 0, "no finished iteration");
+    const uint64_t L = c->L;
+    std::vector<double> buf(LB_PLANES * L), sa(L), sr(L), ne(L);
+    std::vector<uint8_t> m(L);
+    CHK(d2h(c, buf.data(), c->x_locus, LB_PLANES * L * 8));
+    CHK(d2h(c, sa.data(), c->s_alt, L * 8));
+    CHK(d2h(c, sr.data(), c->s_ref, L * 8));
+    CHK(d2h(c, ne.data(), c->n_ent, L * 8));
+    CHK(d2h(c, m.data(), c->mask_next, L));  // the mask this iteration's passes ran under
+    for (uint64_t l = 0; l < L; l++) {
+        const bool live = m[l] != 0;  // a masked locus has no PMFData at all (main.rs:556)
+        const double am = buf[LB_ALT_MIN * L + l], rm = buf[LB_REF_MIN * L + l], cm = buf[LB_CELLS_MIN * L + l];
+        if (cmin) cmin[l] = buf[LB_CONTRIB_MIN * L + l];
+        if (cmaj) cmaj[l] = buf[LB_CONTRIB_MAJ * L + l];
+        if (nmin) nmin[l] = (uint64_t)cm;
+        if (nmaj) nmaj[l] = live ? (uint64_t)(ne[l] - cm) : 0;
+        if (amin) amin[l] = live ? (uint64_t)am : 0;
+        if (rmin) rmin[l] = live ? (uint64_t)rm : 0;
+        if (amaj) amaj[l] = live ? (uint64_t)(sa[l] - am) : 0;
+        if (rmaj) rmaj[l] = live ? (uint64_t)(sr[l] - rm) : 0;
+    }
+    return CELLECTOR_OK;
+}
+
+cellector_status cellector_loci_mask(const cellector_ctx *c, uint8_t *out)
+{
+    if (!c) return CELLECTOR_EINVAL;
+    READY(c);
+    return d2h(c, out, c->mask, c->L);
+}
+
+cellector_status cellector_excluded(const cellector_ctx *c, uint8_t *out)
+{
+    if (!c) return CELLECTOR_EINVAL;
+    READY(c);
+    return d2h(c, out, c->flags, c->nloc);
+}
+
+cellector_status cellector_alpha_betas(const cellector_ctx *c, double *alpha, double *beta)
+{
+    if (!c) return CELLECTOR_EINVAL;
+    READY(c);
+    const uint64_t L = c->L;
+    std::vector<double> buf(LB_PLANES * L), sa(L), sr(L);
+    CHK(d2h(c, buf.data(), c->x_locus, LB_PLANES * L * 8));
+    CHK(d2h(c, sa.data(), c->s_alt, L * 8));
+    CHK(d2h(c, sr.data(), c->s_ref, L * 8));
+    for (uint64_t l = 0; l < L; l++) {
+        if (alpha) alpha[l] = (sa[l] + 1.0) - buf[LB_ALT_MIN * L + l];
+        if (beta) beta[l] = (sr[l] + 1.0) - buf[LB_REF_MIN * L + l];
+    }
+    return CELLECTOR_OK;
+}
+
+cellector_status cellector_cell_log_likelihoods(cellector_ctx *c, const double *alpha, const double *beta,
+                                                const uint8_t *mask, double *ll, double *ell, double *nl)
+{
+    if (!c) return CELLECTOR_EINVAL;
+    READY(c);
+    REQUIRE(c, alpha && beta, "null alpha/beta");
+    REQUIRE(c, c->em_phase == 0, "iteration in flight");
+    SETDEV(c);
+    CHK(launch_ab_from_host(c, alpha, beta, mask));
+    CHK(launch_cell_ll(c, c->ab, nullptr));
+    const size_t b = c->nloc * 8;
+    if (ll) CHK(d2h(c, ll, c->ll, b));
+    if (ell) CHK(d2h(c, ell, c->ell, b));
+    if (nl) CHK(d2h(c, nl, c->nloci, b));
+    if (c->timing) timer_collect(c);
+    return CELLECTOR_OK;
+}
+
+// ---- posteriors ---------------------------------------------------------------------------------------
+cellector_status cellector_posteriors(cellector_ctx *c, double *posterior, double *doublet, double *ll_maj,
+                                      double *ll_min)
+{
+    if (!c) return CELLECTOR_EINVAL;
+    READY(c);
+    REQUIRE(c, c->em_phase == 0, "iteration in flight");
+    SETDEV(c);
+    const double N = (double)c->total_cells;
+    const double mf0 = ((double)c->n_excluded_global + 1.0) / (N + 1.0);  // main.rs:240
+    const double mf = std::fmax(mf0, 0.01);                               // main.rs:250
+    const double lp_dbl = std::log(N / 1000.0 / 100.0 * std::fmax(mf, 0.1));  // main.rs:259
+    const double lp_min = std::log(mf), lp_maj = std::log(1.0 - mf);      // main.rs:264-265
+    CHK(launch_posteriors(c, mf0, lp_min, lp_maj, lp_dbl));
+    const size_t b = c->nloc * 8;
+    if (posterior) CHK(d2h(c, posterior, c->post, b));
+    if (doublet) CHK(d2h(c, doublet, c->post + c->nloc, b));
+    if (ll_maj) CHK(d2h(c, ll_maj, c->post + 2 * c->nloc, b));
+    if (ll_min) CHK(d2h(c, ll_min, c->post + 3 * c->nloc, b));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->timing) timer_collect(c);
+    return CELLECTOR_OK;
+}
+
+cellector_status cellector_final_allele_tallies(cellector_ctx *c, uint64_t *alt_min, uint64_t *ref_min,
+                                                uint64_t *alt_maj, uint64_t *ref_maj)
+{
+    if (!c) return CELLECTOR_EINVAL;
+    READY(c);
+    REQUIRE(c, c->keep_coo, "final tallies need the staged COO (option keep_coo=1)");
+    SETDEV(c);
+    const uint64_t TL = c->total_loci;
+    uint64_t *d = nullptr;
+    CHK(dev_alloc(c, &d, 4 * TL));
+    cellector_status s = launch_final_tallies(c, d);
+    std::vector<uint64_t> h(4 * TL);
+    if (s == CELLECTOR_OK) s = d2h(c, h.data(), d, 4 * TL * 8);
+    dev_free(d);
+    CHK(s);
+    if (alt_min) memcpy(alt_min, h.data(), TL * 8);
+    if (ref_min) memcpy(ref_min, h.data() + TL, TL * 8);
+    if (alt_maj) memcpy(alt_maj, h.data() + 2 * TL, TL * 8);
+    if (ref_maj) memcpy(ref_maj, h.data() + 3 * TL, TL * 8);
+    return CELLECTOR_OK;
+}
+
+// ---- timing -------------------------------------------------------------------------------------------
+cellector_status cellector_kernel_time(cellector_ctx *c, cellector_kernel_id which, double *total_ms, uint64_t *launches)
+{
+    if (!c || which < 0 || which >= CELLECTOR_K_COUNT) return CELLECTOR_EINVAL;
+    (void)hipSetDevice(c->device);
+    timer_collect(c);
+    if (total_ms) *total_ms = c->timers[which].total_ms;
+    if (launches) *launches = c->timers[which].launches;
+    return CELLECTOR_OK;
+}
+
+cellector_status cellector_reset_timing(cellector_ctx *c)
+{
+    if (!c) return CELLECTOR_EINVAL;
+    (void)hipSetDevice(c->device);
+    timer_collect(c);
+    for (int k = 0; k < CELLECTOR_K_COUNT; k++) { c->timers[k].total_ms = 0.0; c->timers[k].launches = 0; }
+    return CELLECTOR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,170 @@
+// Internal state of a cellector_ctx (one shard on one GPU) and the launch wrappers that the
+// C-ABI layer (cellector_ffi.cpp) calls.  Not part of the public ABI.
+#pragma once
+#include <cstring>
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/cellector_ffi.h"
+
+// ---- packed matrix entry -------------------------------------------------------------------
+// CSR (by cell):  bits 0..31 compact locus index, 32..47 alt count, 48..63 ref count
+// CSC (by locus): bits 0..31 local cell index,    32..47 alt count, 48..63 ref count
+#define ENT_IDX(e) ((uint32_t)((e) & 0xffffffffull))
+#define ENT_ALT(e) ((uint32_t)(((e) >> 32) & 0xffffull))
+#define ENT_REF(e) ((uint32_t)((e) >> 48))
+#define CELLECTOR_MAX_COUNT 65535u
+
+// LOCUS exchange buffer layout (f64): 5 planes of L then 8 counters
+enum { LB_CONTRIB_MIN = 0, LB_CONTRIB_MAJ = 1, LB_CELLS_MIN = 2, LB_ALT_MIN = 3, LB_REF_MIN = 4, LB_PLANES = 5 };
+enum { LC_N_NEW = 0, LC_N_RESCUED = 1, LC_N_EXCLUDED = 2, LC_COUNTERS = 8 };
+// PASS1 exchange buffer layout (f64): 5 planes of total_loci
+enum { P1_CELLS_REF = 0, P1_CELLS_ALT = 1, P1_SUM_REF = 2, P1_SUM_ALT = 3, P1_ENTRIES = 4, P1_PLANES = 5 };
+
+#define LF_TABLE_N 171  // ln(FCACHE[0..170]) — statrs ln_factorial cache, SURVEY Appendix B.2
+
+struct KernelTimer {
+    std::vector<hipEvent_t> start, stop;  // pending pairs
+    double total_ms = 0.0;
+    uint64_t launches = 0;
+};
+
+struct cellector_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    mutable std::string err;
+
+    // options
+    bool compute_expected = true;
+    bool timing = false;
+    bool keep_coo = true;
+
+    // shard
+    uint64_t cell_begin = 0, cell_end = UINT64_MAX;
+
+    // dims
+    uint64_t total_loci = 0, total_cells = 0, L = 0, nloc = 0, nnz = 0;
+    enum { ST_EMPTY, ST_STAGED, ST_READY } state = ST_EMPTY;
+    int em_phase = 0;  // 0 idle, 1 after begin, 2 after threshold
+
+    // staged COO of this shard (all loci; cell index local)
+    uint64_t coo_n = 0;
+    uint32_t *coo_locus = nullptr, *coo_cell = nullptr;
+    uint16_t *coo_alt = nullptr, *coo_ref = nullptr;
+    bool coo_sorted = false;
+
+    // matrix
+    uint64_t *csr_ptr = nullptr, *csr_ent = nullptr;  // [nloc+1], [nnz]
+    uint64_t *csc_ptr = nullptr, *csc_ent = nullptr;  // [L+1], [nnz]
+    uint64_t *locus_ids = nullptr;                    // [L]
+    double *s_alt = nullptr, *s_ref = nullptr, *n_ent = nullptr;  // [L] global totals
+    uint64_t *to_used = nullptr;                      // [total_loci] compact index or ~0
+
+    // per-locus loop state
+    double2 *ab = nullptr;       // [L] alpha,beta for the running pass; alpha < 0 => locus masked
+    double *ab6 = nullptr;       // [8L] posterior alpha/beta sets (min, maj, dbl, pad)
+    uint8_t *mask = nullptr;     // [L] loci_used for the current iteration
+    uint8_t *mask_next = nullptr;
+    uint32_t *d_counters = nullptr;  // [8] device scratch counters
+    // per-cell state
+    uint8_t *flags = nullptr, *flags_new = nullptr;  // [nloc] exclusion set
+    double *ll = nullptr, *ell = nullptr, *nloci = nullptr;  // [nloc]
+    double *post = nullptr;  // [4*nloc] posterior, doublet, ll_maj, ll_min
+    double *lf = nullptr;    // [LF_TABLE_N] ln factorial table
+
+    // exchange buffers
+    double *x_pass1 = nullptr, *x_norm = nullptr, *x_locus = nullptr;
+    bool own_pass1 = true, own_norm = true, own_locus = true;
+    uint64_t n_pass1 = 0, n_norm = 0, n_locus = 0;
+
+    // order-statistic workspace
+    uint32_t *sel_hist = nullptr;   // [SEL_T][256]
+    uint64_t *sel_state = nullptr;  // [SEL_T][2] prefix, remaining rank
+    uint64_t *h_sel = nullptr;      // pinned [SEL_T]
+
+    // iteration bookkeeping
+    uint64_t iteration = 0;
+    uint64_t n_excluded_global = 0;
+    double last_median = 0, last_iqr = 0, last_thr = 0;
+    bool have_iter = false;
+
+    KernelTimer timers[CELLECTOR_K_COUNT];
+};
+
+#define SEL_T 6
+
+// ---- error plumbing ---------------------------------------------------------------------------
+cellector_status ctx_fail(const cellector_ctx *c, cellector_status s, const char *fmt, ...);
+#define HIPCHK(c, expr)                                                                          \
+    do {                                                                                         \
+        hipError_t e__ = (expr);                                                                 \
+        if (e__ != hipSuccess)                                                                   \
+            return ctx_fail((c), CELLECTOR_EDEVICE, "%s failed: %s (%s:%d)", #expr,              \
+                            hipGetErrorString(e__), __FILE__, __LINE__);                         \
+    } while (0)
+#define CHK(expr)                                                                                \
+    do {                                                                                         \
+        cellector_status s__ = (expr);                                                           \
+        if (s__ != CELLECTOR_OK) return s__;                                                     \
+    } while (0)
+
+template <typename T>
+static inline cellector_status dev_alloc(cellector_ctx *c, T **p, uint64_t n)
+{
+    void *q = nullptr;
+    hipError_t e = hipMalloc(&q, (n ? n : 1) * sizeof(T));
+    if (e != hipSuccess)
+        return ctx_fail(c, CELLECTOR_ENOMEM, "hipMalloc(%llu bytes) failed: %s",
+                        (unsigned long long)(n * sizeof(T)), hipGetErrorString(e));
+    *p = (T *)q;
+    return CELLECTOR_OK;
+}
+template <typename T>
+static inline void dev_free(T *&p)
+{
+    if (p) (void)hipFree(p);
+    p = nullptr;
+}
+
+// ---- timing -----------------------------------------------------------------------------------
+void timer_begin(cellector_ctx *c, int which);
+void timer_end(cellector_ctx *c, int which);
+void timer_collect(cellector_ctx *c);
+
+// ---- launch wrappers (kernels_*.hip) ------------------------------------------------------------
+// EM loop
+cellector_status launch_alpha_beta(cellector_ctx *c);
+cellector_status launch_cell_ll(cellector_ctx *c, const double2 *ab, double *norm_out /*may be null*/);
+cellector_status launch_flag(cellector_ctx *c, double thr);
+cellector_status launch_locus_stats(cellector_ctx *c);
+cellector_status launch_locus_filter(cellector_ctx *c);
+cellector_status launch_ab_from_host(cellector_ctx *c, const double *alpha, const double *beta,
+                                     const uint8_t *mask);
+cellector_status launch_posteriors(cellector_ctx *c, double mf0, double lp_min, double lp_maj,
+                                   double lp_dbl);
+cellector_status launch_final_tallies(cellector_ctx *c, uint64_t *d_out /*[4*total_loci]*/);
+// order statistics: exact values at SEL_T 0-based ranks of n keys
+cellector_status select_ranks(cellector_ctx *c, const double *keys, uint64_t n,
+                              const uint64_t ranks[SEL_T], double out[SEL_T]);
+// ingest
+cellector_status ingest_stage_host_coo(cellector_ctx *c, uint64_t nnz, const uint32_t *locus0,
+                                       const uint32_t *cell0, const uint32_t *alt, const uint32_t *ref);
+cellector_status ingest_pass1(cellector_ctx *c);
+cellector_status ingest_build(cellector_ctx *c, uint64_t min_alt, uint64_t min_ref);
+cellector_status synth_generate(cellector_ctx *c, double density, uint64_t seed, double minority_fraction,
+                                double doublet_fraction);
+// device helpers
+cellector_status dev_exclusive_scan_u64(cellector_ctx *c, uint64_t *data, uint64_t n, uint64_t *total_out_host);
+cellector_status dev_sort_pairs_u32_u64(cellector_ctx *c, uint32_t *keys_in, uint32_t *keys_out,
+                                        uint64_t *vals_in, uint64_t *vals_out, uint64_t n, int end_bit);
+// host mtx reader (mtx_reader.cpp)
+struct HostCoo {
+    uint64_t total_loci = 0, total_cells = 0;
+    std::vector<uint32_t> locus, cell, alt, ref;
+};
+cellector_status read_mtx_pair(const cellector_ctx *c, const char *alt_path, const char *ref_path, HostCoo *out);

@@ -1,0 +1,393 @@
+// Device ingest: staged COO (this shard's entries, file order) -> locus filter + compaction ->
+// CSC (by locus, file order) and CSR (by cell, file order) of packed 8-byte entries.
+// Replaces get_loci_used (load_data.rs:254-280) and load_cell_data (load_data.rs:134-181).
+//
+// vartrix / combiner write the matrices sorted by (locus, cell) (combiner/src/main.rs:111-115), so a locus'
+// entries are one contiguous run of the file: pass-1 tallies are reduced per run inside a wave before the
+// atomic, and the CSC is the filtered file itself.  Unsorted input is first stably sorted by locus.  The
+// by-cell transpose is a stable LSD radix sort on the cell index (rocPRIM, called once per load).
+#include <cstring>
+
+#include <rocprim/rocprim.hpp>
+
+#include "ctx.h"
+#include "device_math.h"
+
+#define IB 256
+
+// ---------------------------------------------------------------------------------------------------
+// exclusive scan (u64), 2048 elements per block, recursive over block sums
+// ---------------------------------------------------------------------------------------------------
+#define SCAN_ITEMS 8
+#define SCAN_TILE (IB * SCAN_ITEMS)
+
+__global__ __launch_bounds__(IB) void k_scan_block(uint64_t *__restrict__ data, uint64_t n,
+                                                   uint64_t *__restrict__ sums)
+{
+    __shared__ uint64_t wsum[IB / 64];
+    const uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE + (uint64_t)threadIdx.x * SCAN_ITEMS;
+    uint64_t v[SCAN_ITEMS];
+    uint64_t tsum = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; k++) {
+        v[k] = (base + k < n) ? data[base + k] : 0;
+        tsum += v[k];
+    }
+    // inclusive scan of thread sums within the wave
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    uint64_t inc = tsum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        uint64_t o = __shfl_up(inc, off, 64);
+        if (lane >= off) inc += o;
+    }
+    if (lane == 63) wsum[w] = inc;
+    __syncthreads();
+    uint64_t woff = 0, total = 0;
+#pragma unroll
+    for (int k = 0; k < IB / 64; k++) {
+        if (k < w) woff += wsum[k];
+        total += wsum[k];
+    }
+    uint64_t run = woff + inc - tsum;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; k++) {
+        if (base + k < n) data[base + k] = run;
+        run += v[k];
+    }
+    if (threadIdx.x == 0 && sums) sums[blockIdx.x] = total;
+}
+
+__global__ void k_scan_add(uint64_t *__restrict__ data, uint64_t n, const uint64_t *__restrict__ sums)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * SCAN_TILE + threadIdx.x;
+    const uint64_t add = sums[blockIdx.x];
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; k++) {
+        const uint64_t j = i + (uint64_t)k * IB;
+        if (j < n) data[j] += add;
+    }
+}
+
+static cellector_status scan_rec(cellector_ctx *c, uint64_t *data, uint64_t n)
+{
+    const uint64_t nb = (n + SCAN_TILE - 1) / SCAN_TILE;
+    uint64_t *sums = nullptr;
+    if (nb > 1) CHK(dev_alloc(c, &sums, nb));
+    hipLaunchKernelGGL(k_scan_block, dim3((unsigned)nb), dim3(IB), 0, c->stream, data, n, sums);
+    HIPCHK(c, hipGetLastError());
+    if (nb > 1) {
+        CHK(scan_rec(c, sums, nb));
+        hipLaunchKernelGGL(k_scan_add, dim3((unsigned)nb), dim3(IB), 0, c->stream, data, n, sums);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        dev_free(sums);
+    }
+    return CELLECTOR_OK;
+}
+
+// In-place exclusive scan of data[0..n); data[n-1] should be a trailing 0 so that it ends up holding the
+// total, which is also returned to the host.
+cellector_status dev_exclusive_scan_u64(cellector_ctx *c, uint64_t *data, uint64_t n, uint64_t *total_out_host)
+{
+    if (n == 0) {
+        if (total_out_host) *total_out_host = 0;
+        return CELLECTOR_OK;
+    }
+    CHK(scan_rec(c, data, n));
+    if (total_out_host) {
+        HIPCHK(c, hipMemcpyAsync(total_out_host, data + (n - 1), 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    return CELLECTOR_OK;
+}
+
+cellector_status dev_sort_pairs_u32_u64(cellector_ctx *c, uint32_t *keys_in, uint32_t *keys_out, uint64_t *vals_in,
+                                        uint64_t *vals_out, uint64_t n, int end_bit)
+{
+    if (n == 0) return CELLECTOR_OK;
+    size_t tmp_bytes = 0;
+    HIPCHK(c, rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys_in, keys_out, vals_in, vals_out, (size_t)n, 0u,
+                                        (unsigned)end_bit, c->stream));
+    char *tmp = nullptr;
+    CHK(dev_alloc(c, &tmp, tmp_bytes));
+    hipError_t e = rocprim::radix_sort_pairs(tmp, tmp_bytes, keys_in, keys_out, vals_in, vals_out, (size_t)n, 0u,
+                                             (unsigned)end_bit, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    dev_free(tmp);
+    HIPCHK(c, e);
+    return CELLECTOR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// pass 1 (load_data.rs:265-270) + allele totals: per locus, #cells with ref>0, #cells with alt>0, Σref, Σalt,
+// #entries, as f64 (exact: integers < 2^53) into the PASS1 exchange planes.
+// ---------------------------------------------------------------------------------------------------
+template <bool SORTED>
+__global__ __launch_bounds__(IB) void k_pass1(uint64_t n, uint64_t TL, const uint32_t *__restrict__ locus,
+                                              const uint16_t *__restrict__ alt, const uint16_t *__restrict__ ref,
+                                              double *__restrict__ out)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * IB + threadIdx.x;
+    const bool in = i < n;
+    const uint32_t l = in ? locus[i] : 0xffffffffu;
+    const uint32_t a = in ? alt[i] : 0, r = in ? ref[i] : 0;
+    if (!SORTED) {
+        if (!in) return;
+        if (r) { atomicAdd(&out[P1_CELLS_REF * TL + l], 1.0); atomicAdd(&out[P1_SUM_REF * TL + l], (double)r); }
+        if (a) { atomicAdd(&out[P1_CELLS_ALT * TL + l], 1.0); atomicAdd(&out[P1_SUM_ALT * TL + l], (double)a); }
+        atomicAdd(&out[P1_ENTRIES * TL + l], 1.0);
+        return;
+    }
+    const int lane = threadIdx.x & 63;
+    unsigned long long todo = __ballot(in);
+    while (todo) {
+        const int src = __ffsll((long long)todo) - 1;
+        const uint32_t l0 = (uint32_t)__shfl((int)l, src, 64);
+        const bool mine = in && l == l0;
+        const unsigned long long same = __ballot(mine);
+        const uint32_t sa = wave_sum_u32(mine ? a : 0u), sr = wave_sum_u32(mine ? r : 0u);
+        const unsigned long long ba = __ballot(mine && a > 0), br = __ballot(mine && r > 0);
+        if (lane == 0) {
+            if (br) { atomicAdd(&out[P1_CELLS_REF * TL + l0], (double)__popcll(br)); atomicAdd(&out[P1_SUM_REF * TL + l0], (double)sr); }
+            if (ba) { atomicAdd(&out[P1_CELLS_ALT * TL + l0], (double)__popcll(ba)); atomicAdd(&out[P1_SUM_ALT * TL + l0], (double)sa); }
+            atomicAdd(&out[P1_ENTRIES * TL + l0], (double)__popcll(same));
+        }
+        todo &= ~same;
+    }
+}
+
+// locus filter (load_data.rs:273): used flag as u64 for the compaction scan
+__global__ void k_used_flag(uint64_t TL, const double *__restrict__ p1, double min_ref, double min_alt,
+                            uint64_t *__restrict__ flag)
+{
+    const uint64_t l = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (l > TL) return;
+    flag[l] = (l < TL && p1[P1_CELLS_REF * TL + l] >= min_ref && p1[P1_CELLS_ALT * TL + l] >= min_alt) ? 1 : 0;
+}
+
+// to_used[l] holds the exclusive scan; rewrite as compact index or ~0, and gather per-used-locus data
+__global__ void k_compact(uint64_t TL, const double *__restrict__ p1, double min_ref, double min_alt,
+                          uint64_t *__restrict__ to_used, uint64_t *__restrict__ locus_ids,
+                          double *__restrict__ s_alt, double *__restrict__ s_ref, double *__restrict__ n_ent)
+{
+    const uint64_t l = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= TL) return;
+    const bool used = p1[P1_CELLS_REF * TL + l] >= min_ref && p1[P1_CELLS_ALT * TL + l] >= min_alt;
+    const uint64_t u = to_used[l];
+    if (used) {
+        locus_ids[u] = l;
+        s_alt[u] = p1[P1_SUM_ALT * TL + l];
+        s_ref[u] = p1[P1_SUM_REF * TL + l];
+        n_ent[u] = p1[P1_ENTRIES * TL + l];
+    } else {
+        to_used[l] = ~0ull;
+    }
+}
+
+// local entry counts: per cell (used loci only) and per total locus (all entries; gives file rank in locus)
+__global__ __launch_bounds__(IB) void k_count(uint64_t n, const uint32_t *__restrict__ locus,
+                                              const uint32_t *__restrict__ cell, const uint64_t *__restrict__ to_used,
+                                              unsigned long long *__restrict__ row_cnt,
+                                              unsigned long long *__restrict__ loc_cnt)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * IB + threadIdx.x;
+    const bool in = i < n;
+    const uint32_t l = in ? locus[i] : 0xffffffffu;
+    if (in && to_used[l] != ~0ull) atomicAdd(&row_cnt[cell[i]], 1ull);
+    const int lane = threadIdx.x & 63;
+    unsigned long long todo = __ballot(in);
+    while (todo) {  // one atomic per distinct locus per wave (1-2 iterations on locus-sorted input)
+        const int src = __ffsll((long long)todo) - 1;
+        const uint32_t l0 = (uint32_t)__shfl((int)l, src, 64);
+        const unsigned long long same = __ballot(in && l == l0);
+        if (lane == src) atomicAdd(&loc_cnt[l0], (unsigned long long)__popcll(same));
+        todo &= ~same;
+    }
+}
+
+__global__ void k_gather_used_counts(uint64_t L, const uint64_t *__restrict__ locus_ids,
+                                     const uint64_t *__restrict__ loc_cnt, uint64_t *__restrict__ col_cnt)
+{
+    const uint64_t u = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (u > L) return;
+    col_cnt[u] = u < L ? loc_cnt[locus_ids[u]] : 0;
+}
+
+// CSC fill for locus-sorted COO: position = col_ptr[compact locus] + (file index - first file index of the locus)
+__global__ void k_fill(uint64_t n, const uint32_t *__restrict__ locus, const uint32_t *__restrict__ cell,
+                       const uint16_t *__restrict__ alt, const uint16_t *__restrict__ ref,
+                       const uint64_t *__restrict__ to_used, const uint64_t *__restrict__ first_i,
+                       const uint64_t *__restrict__ col_ptr, uint64_t *__restrict__ csc_ent,
+                       uint32_t *__restrict__ key, uint64_t *__restrict__ val)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t l = locus[i];
+    const uint64_t u = to_used[l];
+    if (u == ~0ull) return;
+    const uint64_t pos = col_ptr[u] + (i - first_i[l]);
+    const uint64_t counts = ((uint64_t)alt[i] << 32) | ((uint64_t)ref[i] << 48);
+    const uint32_t cl = cell[i];
+    csc_ent[pos] = (uint64_t)cl | counts;
+    key[pos] = cl;
+    val[pos] = u | counts;
+}
+
+__global__ void k_iota_u64(uint64_t n, uint64_t *__restrict__ v)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) v[i] = i;
+}
+__global__ void k_permute_coo(uint64_t n, const uint64_t *__restrict__ perm, const uint32_t *__restrict__ cell,
+                              const uint16_t *__restrict__ alt, const uint16_t *__restrict__ ref,
+                              uint32_t *__restrict__ cell_o, uint16_t *__restrict__ alt_o, uint16_t *__restrict__ ref_o)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t j = perm[i];
+    cell_o[i] = cell[j]; alt_o[i] = alt[j]; ref_o[i] = ref[j];
+}
+
+static inline unsigned g1(uint64_t n) { return (unsigned)((n + IB - 1) / IB ? (n + IB - 1) / IB : 1); }
+
+// ---------------------------------------------------------------------------------------------------
+cellector_status ingest_stage_host_coo(cellector_ctx *c, uint64_t nnz, const uint32_t *locus0, const uint32_t *cell0,
+                                       const uint32_t *alt, const uint32_t *ref)
+{
+    const uint64_t cb = c->cell_begin, ce = c->cell_end;
+    std::vector<uint32_t> hl, hc;
+    std::vector<uint16_t> ha, hr;
+    hl.reserve(nnz); hc.reserve(nnz); ha.reserve(nnz); hr.reserve(nnz);
+    bool sorted = true;
+    uint32_t prev = 0;
+    for (uint64_t i = 0; i < nnz; i++) {
+        if (locus0[i] >= c->total_loci)
+            return ctx_fail(c, CELLECTOR_EINVAL, "entry %llu: locus %u out of range (total_loci %llu)",
+                            (unsigned long long)i, locus0[i] + 1, (unsigned long long)c->total_loci);
+        if (cell0[i] >= c->total_cells)
+            return ctx_fail(c, CELLECTOR_EINVAL, "entry %llu: cell %u out of range (total_cells %llu)",
+                            (unsigned long long)i, cell0[i] + 1, (unsigned long long)c->total_cells);
+        if (alt[i] > CELLECTOR_MAX_COUNT || ref[i] > CELLECTOR_MAX_COUNT)
+            return ctx_fail(c, CELLECTOR_EINVAL, "entry %llu: count above %u not supported",
+                            (unsigned long long)i, CELLECTOR_MAX_COUNT);
+        if (cell0[i] < cb || cell0[i] >= ce) continue;
+        if (locus0[i] < prev) sorted = false;
+        prev = locus0[i];
+        hl.push_back(locus0[i]); hc.push_back((uint32_t)(cell0[i] - cb));
+        ha.push_back((uint16_t)alt[i]); hr.push_back((uint16_t)ref[i]);
+    }
+    const uint64_t n = hl.size();
+    c->coo_n = n;
+    c->coo_sorted = sorted;
+    CHK(dev_alloc(c, &c->coo_locus, n)); CHK(dev_alloc(c, &c->coo_cell, n));
+    CHK(dev_alloc(c, &c->coo_alt, n)); CHK(dev_alloc(c, &c->coo_ref, n));
+    if (n) {
+        HIPCHK(c, hipMemcpyAsync(c->coo_locus, hl.data(), n * 4, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->coo_cell, hc.data(), n * 4, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->coo_alt, ha.data(), n * 2, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->coo_ref, hr.data(), n * 2, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    return CELLECTOR_OK;
+}
+
+cellector_status ingest_pass1(cellector_ctx *c)
+{
+    const uint64_t TL = c->total_loci;
+    HIPCHK(c, hipMemsetAsync(c->x_pass1, 0, P1_PLANES * TL * 8, c->stream));
+    if (c->coo_n) {
+        if (c->coo_sorted)
+            hipLaunchKernelGGL(k_pass1<true>, dim3(g1(c->coo_n)), dim3(IB), 0, c->stream, c->coo_n, TL, c->coo_locus,
+                               c->coo_alt, c->coo_ref, c->x_pass1);
+        else
+            hipLaunchKernelGGL(k_pass1<false>, dim3(g1(c->coo_n)), dim3(IB), 0, c->stream, c->coo_n, TL, c->coo_locus,
+                               c->coo_alt, c->coo_ref, c->x_pass1);
+        HIPCHK(c, hipGetLastError());
+    }
+    return CELLECTOR_OK;
+}
+
+cellector_status ingest_build(cellector_ctx *c, uint64_t min_alt, uint64_t min_ref)
+{
+    const uint64_t TL = c->total_loci, n = c->coo_n, nloc = c->nloc;
+    // ---- filter + compaction map
+    CHK(dev_alloc(c, &c->to_used, TL + 1));
+    hipLaunchKernelGGL(k_used_flag, dim3(g1(TL + 1)), dim3(IB), 0, c->stream, TL, c->x_pass1, (double)min_ref,
+                       (double)min_alt, c->to_used);
+    HIPCHK(c, hipGetLastError());
+    uint64_t L = 0;
+    CHK(dev_exclusive_scan_u64(c, c->to_used, TL + 1, &L));
+    c->L = L;
+    CHK(dev_alloc(c, &c->locus_ids, L)); CHK(dev_alloc(c, &c->s_alt, L));
+    CHK(dev_alloc(c, &c->s_ref, L)); CHK(dev_alloc(c, &c->n_ent, L));
+    if (TL)
+        hipLaunchKernelGGL(k_compact, dim3(g1(TL)), dim3(IB), 0, c->stream, TL, c->x_pass1, (double)min_ref,
+                           (double)min_alt, c->to_used, c->locus_ids, c->s_alt, c->s_ref, c->n_ent);
+    HIPCHK(c, hipGetLastError());
+
+    // ---- unsorted input: stable sort of the staged COO by locus
+    if (!c->coo_sorted && n) {
+        uint32_t *k_out = nullptr, *cell_o = nullptr;
+        uint16_t *alt_o = nullptr, *ref_o = nullptr;
+        uint64_t *perm = nullptr, *perm_o = nullptr;
+        CHK(dev_alloc(c, &k_out, n)); CHK(dev_alloc(c, &perm, n)); CHK(dev_alloc(c, &perm_o, n));
+        hipLaunchKernelGGL(k_iota_u64, dim3(g1(n)), dim3(IB), 0, c->stream, n, perm);
+        int bits = 1;
+        while (bits < 32 && (1ull << bits) < TL) bits++;
+        CHK(dev_sort_pairs_u32_u64(c, c->coo_locus, k_out, perm, perm_o, n, bits));
+        CHK(dev_alloc(c, &cell_o, n)); CHK(dev_alloc(c, &alt_o, n)); CHK(dev_alloc(c, &ref_o, n));
+        hipLaunchKernelGGL(k_permute_coo, dim3(g1(n)), dim3(IB), 0, c->stream, n, perm_o, c->coo_cell, c->coo_alt,
+                           c->coo_ref, cell_o, alt_o, ref_o);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        dev_free(c->coo_locus); dev_free(c->coo_cell); dev_free(c->coo_alt); dev_free(c->coo_ref);
+        dev_free(perm); dev_free(perm_o);
+        c->coo_locus = k_out; c->coo_cell = cell_o; c->coo_alt = alt_o; c->coo_ref = ref_o;
+        c->coo_sorted = true;
+    }
+
+    // ---- counts and pointers
+    uint64_t *loc_cnt = nullptr, *col_cnt = nullptr;
+    CHK(dev_alloc(c, &c->csr_ptr, nloc + 1));
+    CHK(dev_alloc(c, &loc_cnt, TL + 1));
+    CHK(dev_alloc(c, &c->csc_ptr, L + 1));
+    HIPCHK(c, hipMemsetAsync(c->csr_ptr, 0, (nloc + 1) * 8, c->stream));
+    HIPCHK(c, hipMemsetAsync(loc_cnt, 0, (TL + 1) * 8, c->stream));
+    if (n)
+        hipLaunchKernelGGL(k_count, dim3(g1(n)), dim3(IB), 0, c->stream, n, c->coo_locus, c->coo_cell, c->to_used,
+                           (unsigned long long *)c->csr_ptr, (unsigned long long *)loc_cnt);
+    HIPCHK(c, hipGetLastError());
+    hipLaunchKernelGGL(k_gather_used_counts, dim3(g1(L + 1)), dim3(IB), 0, c->stream, L, c->locus_ids, loc_cnt,
+                       c->csc_ptr);
+    HIPCHK(c, hipGetLastError());
+    uint64_t nnz_rows = 0, nnz_cols = 0;
+    CHK(dev_exclusive_scan_u64(c, c->csr_ptr, nloc + 1, &nnz_rows));
+    CHK(dev_exclusive_scan_u64(c, c->csc_ptr, L + 1, &nnz_cols));
+    CHK(dev_exclusive_scan_u64(c, loc_cnt, TL + 1, nullptr));  // now: first file index of each locus
+    if (nnz_rows != nnz_cols)
+        return ctx_fail(c, CELLECTOR_EDEVICE, "internal: CSR/CSC entry counts differ (%llu vs %llu)",
+                        (unsigned long long)nnz_rows, (unsigned long long)nnz_cols);
+    c->nnz = nnz_rows;
+
+    // ---- CSC = filtered file order; CSR = stable sort of the same entries by cell
+    uint32_t *key = nullptr, *key_o = nullptr;
+    uint64_t *val = nullptr;
+    CHK(dev_alloc(c, &c->csc_ent, c->nnz)); CHK(dev_alloc(c, &c->csr_ent, c->nnz));
+    CHK(dev_alloc(c, &key, c->nnz)); CHK(dev_alloc(c, &key_o, c->nnz)); CHK(dev_alloc(c, &val, c->nnz));
+    if (n)
+        hipLaunchKernelGGL(k_fill, dim3(g1(n)), dim3(IB), 0, c->stream, n, c->coo_locus, c->coo_cell, c->coo_alt,
+                           c->coo_ref, c->to_used, loc_cnt, c->csc_ptr, c->csc_ent, key, val);
+    HIPCHK(c, hipGetLastError());
+    int bits = 1;
+    while (bits < 32 && (1ull << bits) < nloc) bits++;
+    CHK(dev_sort_pairs_u32_u64(c, key, key_o, val, c->csr_ent, c->nnz, bits));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    dev_free(key); dev_free(key_o); dev_free(val); dev_free(loc_cnt);
+    (void)col_cnt;
+    if (!c->keep_coo) {
+        dev_free(c->coo_locus); dev_free(c->coo_cell); dev_free(c->coo_alt); dev_free(c->coo_ref);
+        c->coo_n = 0;
+    }
+    return CELLECTOR_OK;
+}

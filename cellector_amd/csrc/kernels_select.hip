@@ -1,0 +1,149 @@
+// Exact order statistics of N f64 keys on the device (statrs Data::median / Data::quantile need the
+// values at up to six ranks: main.rs:324-327).
+//
+// MSB-first radix select, 8 bits per pass, all SEL_T target ranks refined together: per pass one
+// histogram kernel (keys that match a target's resolved prefix vote into that target's 256-bin LDS
+// histogram; votes are aggregated per wave before the LDS atomic, then per block before the global
+// atomic) and one single-wave kernel that walks each histogram to the bin holding the target rank.
+// Targets that still share a prefix share one histogram (the first of the group computes, the rest copy).
+#include "ctx.h"
+
+#define SEL_BLOCK 256
+#define SEL_PASSES 8
+
+__device__ __forceinline__ uint64_t key_of(double x)
+{
+    uint64_t u = (uint64_t)__double_as_longlong(x);
+    return (u >> 63) ? ~u : (u | 0x8000000000000000ull);  // monotone: order of u == numeric order of x
+}
+__device__ __forceinline__ double value_of(uint64_t k)
+{
+    uint64_t u = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
+    return __longlong_as_double((long long)u);
+}
+
+// state[t] = {prefix (resolved high bits, low bits zero), remaining rank inside that prefix}
+__global__ void k_sel_init(const uint64_t *__restrict__ ranks, uint64_t *__restrict__ state)
+{
+    int t = threadIdx.x;
+    if (t < SEL_T) {
+        state[2 * t] = 0;
+        state[2 * t + 1] = ranks[t];
+    }
+}
+
+__global__ __launch_bounds__(SEL_BLOCK) void k_sel_hist(const double *__restrict__ keys, uint64_t n, int pass,
+                                                        const uint64_t *__restrict__ state,
+                                                        uint32_t *__restrict__ hist)
+{
+    __shared__ uint32_t h[SEL_T][256];
+    __shared__ uint64_t prefix[SEL_T];
+    __shared__ int leader[SEL_T];
+    for (int i = threadIdx.x; i < SEL_T * 256; i += SEL_BLOCK) (&h[0][0])[i] = 0;
+    if (threadIdx.x < SEL_T) prefix[threadIdx.x] = state[2 * threadIdx.x];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int t = 0; t < SEL_T; t++) {
+            int ld = t;
+            for (int u = 0; u < t; u++)
+                if (prefix[u] == prefix[t]) { ld = u; break; }
+            leader[t] = ld;
+        }
+    }
+    __syncthreads();
+    const int shift = 56 - 8 * pass;
+    const uint64_t himask = pass == 0 ? 0ull : (~0ull << (shift + 8));
+    for (uint64_t i = (uint64_t)blockIdx.x * SEL_BLOCK + threadIdx.x; i < n; i += (uint64_t)gridDim.x * SEL_BLOCK) {
+        const uint64_t k = key_of(keys[i]);
+        const uint32_t digit = (uint32_t)(k >> shift) & 0xffu;
+        for (int t = 0; t < SEL_T; t++) {
+            if (leader[t] != t) continue;  // block-uniform
+            bool match = (k & himask) == prefix[t];
+            // wave-aggregated vote: one LDS atomic per distinct digit per wave
+            unsigned long long todo = __ballot(match);
+            while (todo) {
+                const int src = __ffsll((long long)todo) - 1;
+                const uint32_t d0 = (uint32_t)__shfl((int)digit, src, 64);
+                const unsigned long long same = __ballot(match && digit == d0) & todo;
+                if ((threadIdx.x & 63) == src) atomicAdd(&h[t][d0], (uint32_t)__popcll(same));
+                todo &= ~same;
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < SEL_T * 256; i += SEL_BLOCK) {
+        const uint32_t v = (&h[0][0])[i];
+        if (v) atomicAdd(&hist[i], v);
+    }
+}
+
+// one wave: for each target walk its (leader's) histogram to the bin containing the remaining rank
+__global__ void k_sel_step(int pass, uint64_t *__restrict__ state, uint32_t *__restrict__ hist)
+{
+    __shared__ uint64_t prefix[SEL_T];
+    __shared__ uint64_t newst[SEL_T][2];
+    const int t = threadIdx.x;
+    if (t < SEL_T) prefix[t] = state[2 * t];
+    __syncthreads();
+    if (t < SEL_T) {
+        int ld = t;
+        for (int u = 0; u < t; u++)
+            if (prefix[u] == prefix[t]) { ld = u; break; }
+        uint64_t rank = state[2 * t + 1];
+        const uint32_t *h = hist + ld * 256;
+        uint64_t cum = 0;
+        int d = 0;
+        for (; d < 255; d++) {
+            const uint64_t c = h[d];
+            if (cum + c > rank) break;
+            cum += c;
+        }
+        const int shift = 56 - 8 * pass;
+        newst[t][0] = prefix[t] | ((uint64_t)d << shift);
+        newst[t][1] = rank - cum;
+    }
+    __syncthreads();
+    if (t < SEL_T) {
+        state[2 * t] = newst[t][0];
+        state[2 * t + 1] = newst[t][1];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < SEL_T * 256; i += blockDim.x) hist[i] = 0;  // ready for the next pass
+}
+
+__global__ void k_sel_finish(const uint64_t *__restrict__ state, double *__restrict__ out)
+{
+    int t = threadIdx.x;
+    if (t < SEL_T) out[t] = value_of(state[2 * t]);
+}
+
+cellector_status select_ranks(cellector_ctx *c, const double *keys, uint64_t n, const uint64_t ranks[SEL_T],
+                              double out[SEL_T])
+{
+    if (n == 0) return ctx_fail(c, CELLECTOR_EINVAL, "order statistics of an empty array");
+    for (int t = 0; t < SEL_T; t++)
+        if (ranks[t] >= n) return ctx_fail(c, CELLECTOR_EINVAL, "rank %llu out of range", (unsigned long long)ranks[t]);
+    timer_begin(c, CELLECTOR_K_SELECT);
+    // h_sel is pinned: ranks in, values out
+    for (int t = 0; t < SEL_T; t++) c->h_sel[t] = ranks[t];
+    uint64_t *d_ranks = c->sel_state + 2 * SEL_T;  // scratch tail of the state buffer
+    HIPCHK(c, hipMemcpyAsync(d_ranks, c->h_sel, SEL_T * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->sel_hist, 0, SEL_T * 256 * 4, c->stream));
+    hipLaunchKernelGGL(k_sel_init, dim3(1), dim3(64), 0, c->stream, d_ranks, c->sel_state);
+    uint64_t g = (n + SEL_BLOCK * 8 - 1) / (SEL_BLOCK * 8);
+    if (g > 1024) g = 1024;
+    if (g < 1) g = 1;
+    for (int pass = 0; pass < SEL_PASSES; pass++) {
+        hipLaunchKernelGGL(k_sel_hist, dim3((unsigned)g), dim3(SEL_BLOCK), 0, c->stream, keys, n, pass, c->sel_state,
+                           c->sel_hist);
+        hipLaunchKernelGGL(k_sel_step, dim3(1), dim3(64), 0, c->stream, pass, c->sel_state, c->sel_hist);
+    }
+    double *d_out = reinterpret_cast<double *>(d_ranks);
+    hipLaunchKernelGGL(k_sel_finish, dim3(1), dim3(64), 0, c->stream, c->sel_state, d_out);
+    timer_end(c, CELLECTOR_K_SELECT);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(c->h_sel, d_out, SEL_T * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (int t = 0; t < SEL_T; t++) memcpy(&out[t], &c->h_sel[t], 8);
+    return CELLECTOR_OK;
+}

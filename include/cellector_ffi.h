@@ -1,0 +1,188 @@
+/*
+ * cellector_ffi.h — C ABI of libcellector_hip.so: the MI355X (gfx950) implementation of
+ * cellector's genotype-likelihood / EM scoring path.
+ *
+ * The reference (wheaton5/cellector, Rust, single-threaded CPU) has no FFI of its own; the seams
+ * below are the reference's own function boundaries, so a Rust host replaces each call with one
+ * `extern "C"` call (binding shown in INTEGRATION.md).  Citations are file:line under
+ * /root/reference/cellector/src/.
+ *
+ * Conventions
+ *  - every function returns a cellector_status and never throws or aborts across the boundary;
+ *    cellector_last_error(ctx) gives the message (the reference panics -> stderr + exit 101);
+ *  - plain pointers and sizes only; host output buffers are caller-allocated and caller-owned;
+ *  - a ctx owns all device memory, is bound to one GPU, and is driven by one host thread at a time;
+ *  - a ctx holds ONE SHARD of the matrix: the cells [cell_begin, cell_end) of the global cell
+ *    range, all loci.  Per-locus state is replicated on every shard.  Multi-GPU = one process per
+ *    GPU, one ctx each; the three exchange buffers below are all-reduced (f64 sum) by the host
+ *    (torch.distributed/RCCL) at the marked points.  With a single shard nothing is exchanged and
+ *    cellector_em_iteration() runs the three phases back to back;
+ *  - every kernel is launched on the ctx's stream (default: the null stream).
+ */
+#ifndef CELLECTOR_FFI_H
+#define CELLECTOR_FFI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct cellector_ctx cellector_ctx;
+
+typedef enum {
+    CELLECTOR_OK = 0,
+    CELLECTOR_EINVAL = 1,  /* bad argument / call out of order            */
+    CELLECTOR_EIO = 2,     /* cannot open/read a file (reader, load_data.rs:240-251) */
+    CELLECTOR_EPARSE = 3,  /* malformed mtx text (read_mtx_lines, load_data.rs:190-204) */
+    CELLECTOR_ENOMEM = 4,
+    CELLECTOR_EDEVICE = 5, /* HIP runtime error                            */
+    CELLECTOR_ECOMM = 6
+} cellector_status;
+
+/* ---- lifecycle ----------------------------------------------------------------------------- */
+cellector_status cellector_create(cellector_ctx **out, int device_id);
+void cellector_destroy(cellector_ctx *ctx);
+const char *cellector_last_error(const cellector_ctx *ctx); /* ctx-owned, valid until next call */
+const char *cellector_version(void);
+/* hipStream_t to launch on (e.g. torch.cuda.current_stream().cuda_stream); NULL = null stream. */
+cellector_status cellector_set_stream(cellector_ctx *ctx, void *hip_stream);
+/* Options: "compute_expected" (default 1: also accumulate expected_log_beta_binomial_pmf,
+ * stats.rs:8-33, into expected_ll like the reference; 0 = skip that diagnostic column),
+ * "timing" (default 0: record HIP events around the dominant kernels). */
+cellector_status cellector_set_option(cellector_ctx *ctx, const char *key, int64_t value);
+
+/* ---- sharding (before ingest) --------------------------------------------------------------- */
+/* This ctx owns global cells [cell_begin, cell_end).  Default: all cells. */
+cellector_status cellector_set_shard(cellector_ctx *ctx, uint64_t cell_begin, uint64_t cell_end);
+
+/* ---- ingest: replaces load_cell_data (load_data.rs:134-181) + get_loci_used (:254-280) ------- */
+/* Phase 1 — stage this shard's entries on the device and count, per locus, cells with ref>0 /
+ * alt>0 (pass 1, load_data.rs:265-270) and the allele totals into CELLECTOR_XCHG_PASS1. */
+cellector_status cellector_ingest_mtx(cellector_ctx *ctx, const char *alt_path, const char *ref_path);
+/* Caller COO in file order, 0-based indices (any order; locus-major like vartrix is fastest). */
+cellector_status cellector_ingest_coo(cellector_ctx *ctx, uint64_t total_loci, uint64_t total_cells,
+                                      uint64_t nnz, const uint32_t *locus0, const uint32_t *cell0,
+                                      const uint32_t *alt, const uint32_t *ref);
+/* Deterministic synthetic vartrix-like matrix generated on the device (benchmarks; definition in
+ * DESIGN.md / cellector_amd/synth.py, which produces bit-identical host data). */
+cellector_status cellector_ingest_synthetic(cellector_ctx *ctx, uint64_t total_loci,
+                                            uint64_t total_cells, double density, uint64_t seed,
+                                            double minority_fraction, double doublet_fraction);
+/* >>> multi-shard: all-reduce CELLECTOR_XCHG_PASS1 here <<< */
+/* Phase 2 — locus filter `cells_ref >= min_ref && cells_alt >= min_alt` (load_data.rs:273),
+ * compaction, CSR (by cell) + CSC (by locus) build on the device (pass 2, load_data.rs:151-174). */
+cellector_status cellector_ingest_finish(cellector_ctx *ctx, uint64_t min_alt, uint64_t min_ref);
+/* Single-shard conveniences = ingest + finish. */
+cellector_status cellector_load_mtx(cellector_ctx *ctx, const char *alt_path, const char *ref_path,
+                                    uint64_t min_alt, uint64_t min_ref);
+cellector_status cellector_load_coo(cellector_ctx *ctx, uint64_t total_loci, uint64_t total_cells,
+                                    uint64_t nnz, const uint32_t *locus0, const uint32_t *cell0,
+                                    const uint32_t *alt, const uint32_t *ref, uint64_t min_alt,
+                                    uint64_t min_ref);
+
+typedef struct {
+    uint64_t total_cells, total_loci; /* header dims (consume_mtx_header, load_data.rs:206-223) */
+    uint64_t loci_used;               /* L = loci passing the filter                            */
+    uint64_t cell_begin, cell_end;    /* this shard                                             */
+    uint64_t nnz_used;                /* this shard's entries at used loci                      */
+} cellector_dims_t;
+cellector_status cellector_dims(const cellector_ctx *ctx, cellector_dims_t *out);
+cellector_status cellector_locus_ids(const cellector_ctx *ctx, uint64_t *out /*[L]*/);
+/* locus_counts of load_cell_data: out[2l] = sum ref, out[2l+1] = sum alt (load_data.rs:157-158) */
+cellector_status cellector_locus_counts(const cellector_ctx *ctx, double *out /*[2L]*/);
+/* cell.cell_loci_data.len() for the min_loci_for_assignment rule (main.rs:153) */
+cellector_status cellector_entries_per_cell(const cellector_ctx *ctx, uint32_t *out /*[local cells]*/);
+/* CSR rows of local cells [row_begin,row_end): row_ptr rebased to 0, entries packed
+ * locus_index | alt << 32 | ref << 48 (diagnostics, tests, CPU-baseline sampling). */
+cellector_status cellector_csr_rows(const cellector_ctx *ctx, uint64_t row_begin, uint64_t row_end,
+                                    uint64_t *row_ptr /*[rows+1]*/, uint64_t *entries, uint64_t capacity);
+
+/* ---- exchange buffers (device memory, f64) --------------------------------------------------- */
+typedef enum {
+    CELLECTOR_XCHG_PASS1 = 0, /* [5*total_loci]: cells_ref | cells_alt | sum_ref | sum_alt | n_entries */
+    CELLECTOR_XCHG_NORM = 1,  /* [total_cells]: normalised LL of every cell (own slice written, rest 0) */
+    CELLECTOR_XCHG_LOCUS = 2  /* [5*L+8]: contrib_min | contrib_maj | cells_min | alt_min | ref_min |
+                                 {n_new, n_rescued, n_excluded, ...}                               */
+} cellector_xchg;
+cellector_status cellector_exchange_buffer(cellector_ctx *ctx, cellector_xchg which, void **dev_ptr,
+                                           uint64_t *n_f64);
+/* Use caller-allocated device memory (e.g. a torch tensor) for an exchange buffer; must be called
+ * before the buffer is first used (PASS1: after cellector_set_shard; NORM/LOCUS: after ingest_finish
+ * sizes are known via cellector_exchange_buffer with dev_ptr == NULL). */
+cellector_status cellector_bind_exchange_buffer(cellector_ctx *ctx, cellector_xchg which,
+                                                void *dev_ptr, uint64_t n_f64);
+
+/* ---- one EM iteration == compute_new_excluded (main.rs:308-347) ------------------------------ */
+typedef struct {
+    int32_t any_change;                /* main.rs:335                                            */
+    uint64_t n_new_excluded, n_rescued; /* main.rs:333-334                                       */
+    uint64_t n_excluded;               /* |new exclusion set| over all shards                    */
+    uint64_t n_loci_filtered;          /* loci newly masked by the -80 filter (main.rs:444-447)  */
+    double median, iqr, threshold;     /* main.rs:325-329                                        */
+} cellector_iter_summary;
+
+/* phase A: init_alpha_betas (main.rs:598-611) from the previous exclusion set's tallies, then
+ * get_cell_log_likelihoods (main.rs:541-591) over this shard's cells and the normalisation of
+ * main.rs:314-323 into this shard's slice of CELLECTOR_XCHG_NORM. */
+cellector_status cellector_em_begin(cellector_ctx *ctx);
+/* >>> multi-shard: all-reduce CELLECTOR_XCHG_NORM here <<< */
+/* phase B: exact median / R-8 quartiles over all cells (statrs Data, main.rs:324-327), threshold
+ * (main.rs:328-329), new exclusion flags of this shard's cells (main.rs:330-332) and this shard's
+ * part of get_locus_log_likelihoods (main.rs:368-420) into CELLECTOR_XCHG_LOCUS. */
+cellector_status cellector_em_threshold(cellector_ctx *ctx, double iqr_multiple);
+/* >>> multi-shard: all-reduce CELLECTOR_XCHG_LOCUS here <<< */
+/* phase C: locus filter (main.rs:428-451), any_change, state swap. */
+cellector_status cellector_em_finish(cellector_ctx *ctx, cellector_iter_summary *out);
+/* single shard: A, B, C back to back */
+cellector_status cellector_em_iteration(cellector_ctx *ctx, double iqr_multiple,
+                                        cellector_iter_summary *out);
+
+/* outputs of the last iteration (host buffers; any pointer may be NULL) */
+cellector_status cellector_iter_cell_outputs(const cellector_ctx *ctx, double *ll, double *expected_ll,
+                                             double *loci_used_per_cell,
+                                             double *normalized /*[local cells] each*/);
+/* LocusLogLikelihoodData (main.rs:516-525) after the exchange, global over all shards */
+cellector_status cellector_iter_locus_outputs(const cellector_ctx *ctx, double *contrib_min,
+                                              double *contrib_maj, uint64_t *cells_min,
+                                              uint64_t *cells_maj, uint64_t *alt_min,
+                                              uint64_t *ref_min, uint64_t *alt_maj,
+                                              uint64_t *ref_maj /*[L] each*/);
+cellector_status cellector_loci_mask(const cellector_ctx *ctx, uint8_t *out /*[L]*/);
+cellector_status cellector_excluded(const cellector_ctx *ctx, uint8_t *out /*[local cells]*/);
+/* alpha/beta that the NEXT em_begin will use = init_alpha_betas(current excluded), main.rs:598 */
+cellector_status cellector_alpha_betas(const cellector_ctx *ctx, double *alpha, double *beta /*[L]*/);
+
+/* get_cell_log_likelihoods (main.rs:541-591) alone under caller alpha/beta/mask (host arrays). */
+cellector_status cellector_cell_log_likelihoods(cellector_ctx *ctx, const double *alpha,
+                                                const double *beta, const uint8_t *mask /*[L] or NULL*/,
+                                                double *ll, double *expected_ll,
+                                                double *loci_used_per_cell /*[local cells]*/);
+
+/* ---- calculate_posteriors (main.rs:228-280) with the current exclusion set -------------------- */
+cellector_status cellector_posteriors(cellector_ctx *ctx, double *posterior, double *doublet_posterior,
+                                      double *ll_majority, double *ll_minority /*[local cells]*/);
+
+/* ---- load_mtx_final (load_data.rs:109-132): per-locus allele tallies over ALL loci split by the
+ * current exclusion set, for output_final_vcf (main.rs:52-131).  This shard's cells only; sum
+ * across shards on the host. */
+cellector_status cellector_final_allele_tallies(cellector_ctx *ctx, uint64_t *alt_min, uint64_t *ref_min,
+                                                uint64_t *alt_maj, uint64_t *ref_maj /*[total_loci]*/);
+
+/* ---- timing of the dominant kernels (HIP events on the ctx stream; option "timing") ---------- */
+typedef enum {
+    CELLECTOR_K_CELL_LL = 0,     /* per-cell log-likelihood pass over the CSR  */
+    CELLECTOR_K_LOCUS_STATS = 1, /* per-locus pass over the CSC                */
+    CELLECTOR_K_SELECT = 2,      /* order statistics                           */
+    CELLECTOR_K_POSTERIOR = 3,   /* fused 3-distribution pass + posteriors     */
+    CELLECTOR_K_COUNT = 4
+} cellector_kernel_id;
+cellector_status cellector_kernel_time(cellector_ctx *ctx, cellector_kernel_id which,
+                                       double *total_ms, uint64_t *launches);
+cellector_status cellector_reset_timing(cellector_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

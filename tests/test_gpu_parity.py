@@ -1,0 +1,325 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on the same seeded inputs.
+
+Tolerances (north_star: assignments bit-exact, posteriors within 1e-6):
+  * integer / index / flag outputs: exact;
+  * per-cell log-likelihood sums: abs 1e-7 (the oracle's own ln_gamma-difference cancellation noise is
+    ~1e-11 per entry; the device uses the exact product form, see csrc/device_math.h);
+  * posteriors: abs 1e-6.
+Cells whose normalised LL lies within 1e-9 of the threshold would be reported as near-ties (none occur on
+these inputs; the test asserts that so a flip can never hide).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+LL_ATOL = 1e-7
+POST_ATOL = 1e-6
+
+
+@pytest.fixture(scope="module")
+def mods(oracle_lib, hip_lib_path):
+    from cellector_amd import Cellector, ffi, synth
+    return dict(Cellector=Cellector, ffi=ffi, synth=synth, ob=oracle_lib)
+
+
+def _case(mods, L, N, d, seed=4, minority=0.05, doublet=0.0, min_alt=4, min_ref=4):
+    lo, ce, al, re = mods["synth"].generate_coo(L, N, d, seed=seed, minority_fraction=minority,
+                                                 doublet_fraction=doublet)
+    g = mods["Cellector"](0)
+    g.load_coo(L, N, lo, ce, al, re, min_alt, min_ref)
+    o = mods["ob"].Oracle.from_coo(L, N, lo, ce, al, re, min_alt, min_ref)
+    return g, o, (lo, ce, al, re)
+
+
+def _check_matrix(g, o):
+    d = g.dims()
+    assert (d.total_cells, d.total_loci, d.loci_used, d.nnz_used) == (o.total_cells, o.total_loci, o.loci_used, o.nnz)
+    assert np.array_equal(g.locus_ids(), o.locus_ids())
+    assert np.array_equal(g.locus_counts(), o.locus_counts())
+    assert np.array_equal(g.entries_per_cell(), o.entries_per_cell())
+    rp, ent = g.csr_rows(0, o.total_cells)
+    assert np.array_equal(rp, o.row_ptr())
+    li, a, r, _ = o.entries()
+    assert np.array_equal(ent & np.uint64(0xFFFFFFFF), li.astype(np.uint64))
+    assert np.array_equal((ent >> np.uint64(32)) & np.uint64(0xFFFF), a.astype(np.uint64))
+    assert np.array_equal(ent >> np.uint64(48), r.astype(np.uint64))
+
+
+def _check_iteration(g, o, sg, so):
+    cg, co = g.cell_outputs(), o.cell_outputs()
+    assert np.array_equal(cg["loci_used"], co["loci_used"])
+    np.testing.assert_allclose(cg["ll"], co["ll"], rtol=0, atol=LL_ATOL)
+    np.testing.assert_allclose(cg["expected_ll"], co["expected_ll"], rtol=0, atol=LL_ATOL)
+    np.testing.assert_allclose(cg["normalized"], co["normalized"], rtol=0, atol=1e-9)
+    np.testing.assert_allclose([sg.median, sg.iqr, sg.threshold], [so.median, so.iqr, so.threshold], rtol=0, atol=1e-9)
+    near = np.abs(co["normalized"] - so.threshold) < 1e-9
+    assert not near.any(), f"near-tie cells at the threshold: {np.nonzero(near)[0]}"
+    assert np.array_equal(g.excluded(), o.excluded())
+    assert (sg.any_change, sg.n_new_excluded, sg.n_rescued) == (so.any_change, so.n_new_excluded, so.n_rescued)
+    assert sg.n_excluded == int(o.excluded().sum())
+    lg, lo_ = g.locus_outputs(), o.locus_outputs()
+    for k in ("cells_min", "cells_maj", "alt_min", "ref_min", "alt_maj", "ref_maj"):
+        assert np.array_equal(lg[k], lo_[k]), k
+    np.testing.assert_allclose(lg["contrib_min"], lo_["contrib_min"], rtol=0, atol=LL_ATOL)
+    np.testing.assert_allclose(lg["contrib_maj"], lo_["contrib_maj"], rtol=0, atol=1e-6)
+    assert np.array_equal(g.loci_mask(), o.loci_mask())
+    assert sg.n_loci_filtered == so.n_loci_filtered
+    ag, bg = g.alpha_betas()
+    ao, bo = o.alpha_betas()
+    assert np.array_equal(ag, ao) and np.array_equal(bg, bo)
+
+
+def _run_both(g, o, max_iter=30):
+    n = 0
+    while True:
+        sg, so = g.em_iteration(5.0), o.em_iteration(5.0)
+        _check_iteration(g, o, sg, so)
+        n += 1
+        if not so.any_change or n >= max_iter:
+            return n
+
+
+def _check_posteriors(mods, g, o):
+    pg, po = g.posteriors(), o.posteriors()
+    for k in ("ll_majority", "ll_minority"):
+        np.testing.assert_allclose(pg[k], po[k], rtol=0, atol=LL_ATOL)
+    np.testing.assert_allclose(pg["posterior"], po["posterior"], rtol=0, atol=POST_ATOL)
+    np.testing.assert_allclose(pg["doublet_posterior"], po["doublet_posterior"], rtol=0, atol=POST_ATOL)
+    ga = mods["ffi"].assignments(pg["posterior"], pg["doublet_posterior"], g.entries_per_cell(), g.excluded())
+    oa = o.assignments(po["posterior"], po["doublet_posterior"])
+    # bit-exact labels; qual may differ by one unit only where -10 log10(1-p) sits on an integer boundary
+    assert np.array_equal(ga[0], oa[0]) and np.array_equal(ga[1], oa[1])
+    assert np.max(np.abs(ga[2].astype(np.int64) - oa[2].astype(np.int64))) <= 1
+    return pg, po
+
+
+def test_synthetic_generator_matches_host_twin(mods):
+    L, N, d = 300, 40000, 0.02  # spans three 16384-cell generator tiles
+    lo, ce, al, re = mods["synth"].generate_coo(L, N, d, seed=11, minority_fraction=0.07, doublet_fraction=0.02)
+    with mods["Cellector"](0) as g:
+        g.load_synthetic(L, N, d, seed=11, minority_fraction=0.07, doublet_fraction=0.02, min_alt=0, min_ref=0)
+        o = mods["ob"].Oracle.from_coo(L, N, lo, ce, al, re, 0, 0)
+        _check_matrix(g, o)
+
+
+def test_cfg1_full_loop_and_posteriors(mods):
+    g, o, _ = _case(mods, 2000, 1000, 0.10)
+    _check_matrix(g, o)
+    assert 0 < o.loci_used < 2000  # the min_ref/min_alt filter really drops loci here
+    iters = _run_both(g, o)
+    assert iters >= 2 and o.excluded().sum() > 0
+    _check_posteriors(mods, g, o)
+    g.close()
+
+
+def test_doublets_and_small_minority(mods):
+    g, o, _ = _case(mods, 3000, 1500, 0.08, seed=7, minority=0.1, doublet=0.03)
+    _run_both(g, o)
+    pg, po = _check_posteriors(mods, g, o)
+    g.close()
+
+
+def test_ll_pass_under_caller_alpha_beta_and_mask(mods):
+    g, o, _ = _case(mods, 1500, 800, 0.1, seed=3)
+    rng = np.random.default_rng(0)
+    L = o.loci_used
+    alpha = rng.uniform(0.5, 5000.0, L)   # non-integer alpha/beta like the posterior phase
+    beta = rng.uniform(0.5, 5000.0, L)
+    mask = (rng.random(L) > 0.3).astype(np.uint8)
+    for m in (None, mask):
+        lg = g.cell_log_likelihoods(alpha, beta, m)
+        lo_ = o.cell_log_likelihoods(alpha, beta, m)
+        np.testing.assert_allclose(lg[0], lo_[0], rtol=0, atol=LL_ATOL)
+        np.testing.assert_allclose(lg[1], lo_[1], rtol=0, atol=LL_ATOL)
+        assert np.array_equal(lg[2], lo_[2])
+    g.close()
+
+
+def test_edge_counts_and_empty_cells(mods):
+    """Hand-built matrix: zero/zero entries (quirk Q14), counts far above the 8-factor fast path, totals above
+    the 170-entry factorial cache, cells without entries (quirk Q4), unsorted input order."""
+    rng = np.random.default_rng(5)
+    L, N = 40, 300
+    lo, ce, al, re = [], [], [], []
+    for l in range(L):
+        for c in range(N):
+            if c % 7 == 3:          # cells with no entries at all
+                continue
+            if rng.random() < 0.5:
+                big = rng.random() < 0.15
+                a = int(rng.integers(0, 120 if big else 4))
+                r = int(rng.integers(0, 120 if big else 4))
+                lo.append(l); ce.append(c); al.append(a); re.append(r)
+    lo, ce, al, re = map(lambda x: np.array(x, np.uint32), (lo, ce, al, re))
+    al[5], re[5] = 0, 0
+    al[17], re[17] = 150, 90       # n = 240 > 170: ln_gamma branch of ln_factorial
+    perm = rng.permutation(len(lo))  # file order not sorted by locus
+    lo, ce, al, re = lo[perm], ce[perm], al[perm], re[perm]
+    g = mods["Cellector"](0)
+    g.load_coo(L, N, lo, ce, al, re, 1, 1)
+    o = mods["ob"].Oracle.from_coo(L, N, lo, ce, al, re, 1, 1)
+    d = g.dims()
+    assert (d.loci_used, d.nnz_used) == (o.loci_used, o.nnz)
+    assert np.array_equal(g.locus_ids(), o.locus_ids())
+    assert np.array_equal(g.locus_counts(), o.locus_counts())
+    assert np.array_equal(g.entries_per_cell(), o.entries_per_cell())
+    assert (g.entries_per_cell() == 0).sum() >= N // 7
+    _run_both(g, o, max_iter=6)
+    _check_posteriors(mods, g, o)
+    g.close()
+
+
+def test_locus_filter_triggers(mods):
+    """A locus where the minority population is fixed for the other allele with deep coverage contributes far
+    below -80 per minority cell and must be masked from the next iteration on (main.rs:444-447)."""
+    L, N = 400, 600
+    lo, ce, al, re = mods["synth"].generate_coo(L, N, 0.25, seed=9, minority_fraction=0.1)
+    cls = mods["synth"].cell_classes(N, seed=9, minority_fraction=0.1)
+    extra_l = np.full(N, L, np.uint32)            # one extra, pathological locus
+    extra_c = np.arange(N, dtype=np.uint32)
+    extra_a = np.where(cls == 1, 60, 0).astype(np.uint32)
+    extra_r = np.where(cls == 1, 0, 60).astype(np.uint32)
+    lo = np.concatenate([lo, extra_l]); ce = np.concatenate([ce, extra_c])
+    al = np.concatenate([al, extra_a]); re = np.concatenate([re, extra_r])
+    g = mods["Cellector"](0)
+    g.load_coo(L + 1, N, lo, ce, al, re)
+    o = mods["ob"].Oracle.from_coo(L + 1, N, lo, ce, al, re)
+    _run_both(g, o)
+    assert (o.loci_mask() == 0).sum() >= 1
+    _check_posteriors(mods, g, o)
+    g.close()
+
+
+def test_mtx_files_plain_and_gz(mods, tmp_path):
+    L, N = 500, 400
+    lo, ce, al, re = mods["synth"].generate_coo(L, N, 0.15, seed=2)
+    for gz in (False, True):
+        a_path, r_path = mods["synth"].write_mtx_pair(str(tmp_path / ("gz" if gz else "plain")), L, N, lo, ce, al, re,
+                                                      gz=gz, header_nnz=0)
+        g = mods["Cellector"](0)
+        g.load_mtx(a_path, r_path)
+        o = mods["ob"].Oracle.from_mtx(a_path, r_path)
+        _check_matrix(g, o)
+        sg, so = g.em_iteration(5.0), o.em_iteration(5.0)
+        _check_iteration(g, o, sg, so)
+        g.close()
+    g = mods["Cellector"](0)
+    with pytest.raises(mods["ffi"].CellectorError) as ei:
+        g.load_mtx(str(tmp_path / "missing.mtx"), str(tmp_path / "missing.mtx"))
+    assert "couldn't open file" in str(ei.value)
+    bad = tmp_path / "bad.mtx"
+    bad.write_text("%%MatrixMarket matrix coordinate real general\n%\n3 3 1\n1 1 1.0\n")
+    with pytest.raises(mods["ffi"].CellectorError):
+        g.load_mtx(str(bad), str(bad))
+    g.close()
+
+
+# ---- two shards on one GPU, exchange done by hand through the host ------------------------------------------
+def _hip():
+    lib = C.CDLL("libamdhip64.so")
+    lib.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    lib.hipMemcpy.restype = C.c_int
+    return lib
+
+
+def _allreduce(hip, shards, which):
+    bufs = [s.exchange_buffer(which) for s in shards]
+    n = bufs[0][1]
+    tot = np.zeros(n, np.float64)
+    tmp = np.empty(n, np.float64)
+    for ptr, _ in bufs:
+        assert hip.hipMemcpy(tmp.ctypes.data, ptr, n * 8, 2) == 0  # D2H
+        tot += tmp
+    for ptr, _ in bufs:
+        assert hip.hipMemcpy(ptr, tot.ctypes.data, n * 8, 1) == 0  # H2D
+
+
+def test_two_shards_equal_single_shard(mods):
+    L, N, d = 1500, 1201, 0.1
+    lo, ce, al, re = mods["synth"].generate_coo(L, N, d, seed=4, minority_fraction=0.06, doublet_fraction=0.01)
+    hip = _hip()
+    single = mods["Cellector"](0)
+    single.load_coo(L, N, lo, ce, al, re)
+    cut = 523
+    shards = [mods["Cellector"](0), mods["Cellector"](0)]
+    shards[0].set_shard(0, cut)
+    shards[1].set_shard(cut, N)
+    for s in shards:
+        s.ingest_coo(L, N, lo, ce, al, re)
+    _allreduce(hip, shards, mods["ffi"].XCHG_PASS1)
+    for s in shards:
+        s.ingest_finish()
+    assert shards[0].dims().loci_used == single.dims().loci_used
+    assert shards[0].dims().nnz_used + shards[1].dims().nnz_used == single.dims().nnz_used
+    for it in range(30):
+        s1 = single.em_iteration(5.0)
+        for s in shards:
+            s.em_begin()
+        _allreduce(hip, shards, mods["ffi"].XCHG_NORM)
+        for s in shards:
+            s.em_threshold(5.0)
+        _allreduce(hip, shards, mods["ffi"].XCHG_LOCUS)
+        ss = [s.em_finish() for s in shards]
+        for s2 in ss:
+            assert (s2.any_change, s2.n_new_excluded, s2.n_rescued, s2.n_excluded, s2.n_loci_filtered) == \
+                   (s1.any_change, s1.n_new_excluded, s1.n_rescued, s1.n_excluded, s1.n_loci_filtered)
+            assert (s2.median, s2.iqr, s2.threshold) == (s1.median, s1.iqr, s1.threshold)
+        ex = np.concatenate([s.excluded() for s in shards])
+        assert np.array_equal(ex, single.excluded())
+        c1 = single.cell_outputs()
+        for k in c1:
+            assert np.array_equal(np.concatenate([s.cell_outputs()[k] for s in shards]), c1[k]), k
+        l1, l2 = single.locus_outputs(), shards[1].locus_outputs()
+        for k in l1:
+            if k.startswith("contrib"):
+                np.testing.assert_allclose(l2[k], l1[k], rtol=0, atol=1e-8)
+            else:
+                assert np.array_equal(l2[k], l1[k]), k
+        if not s1.any_change:
+            break
+    p1 = single.posteriors()
+    p2 = [s.posteriors() for s in shards]
+    for k in p1:
+        assert np.array_equal(np.concatenate([p[k] for p in p2]), p1[k]), k
+    for s in shards + [single]:
+        s.close()
+
+
+def test_medium_matrix_properties_and_parity(mods):
+    """20k cells x 20k loci at 1% (device-generated, ~4e6 entries): oracle parity for the first iteration and
+    the size-independent properties the path offers."""
+    L, N, d = 20000, 20000, 0.01
+    g = mods["Cellector"](0)
+    g.load_synthetic(L, N, d, seed=4, minority_fraction=0.05)
+    dm = g.dims()
+    rp, ent = g.csr_rows(0, N)
+    lc = g.locus_counts()
+    o = mods["ob"].Oracle.from_csr(dm.loci_used, rp, ent, lc)
+    # conservation: the per-locus totals equal the column sums of the CSR
+    li = (ent & np.uint64(0xFFFFFFFF)).astype(np.int64)
+    alt = ((ent >> np.uint64(32)) & np.uint64(0xFFFF)).astype(np.float64)
+    ref = (ent >> np.uint64(48)).astype(np.float64)
+    assert np.array_equal(np.bincount(li, alt, dm.loci_used), lc[:, 1])
+    assert np.array_equal(np.bincount(li, ref, dm.loci_used), lc[:, 0])
+    sg, so = g.em_iteration(5.0), o.em_iteration(5.0)
+    cg, co = g.cell_outputs(), o.cell_outputs()
+    np.testing.assert_allclose(cg["ll"], co["ll"], rtol=0, atol=LL_ATOL)
+    np.testing.assert_allclose(cg["expected_ll"], co["expected_ll"], rtol=0, atol=LL_ATOL)
+    assert np.array_equal(g.excluded(), o.excluded())
+    # the cell pass and the locus pass see the same log-pmfs: Σ_cells LL == Σ_loci (contrib_min + contrib_maj)
+    lg = g.locus_outputs()
+    assert abs(cg["ll"].sum() - (lg["contrib_min"].sum() + lg["contrib_maj"].sum())) < 1e-5
+    assert int(lg["cells_min"].sum() + lg["cells_maj"].sum()) == dm.nnz_used
+    # idempotence at the fixed point: once nothing changes, another iteration reproduces the same state
+    summaries = g.run(5.0, max_iter=30)
+    assert not summaries[-1].any_change
+    ex = g.excluded().copy()
+    s2 = g.em_iteration(5.0)
+    assert not s2.any_change and np.array_equal(g.excluded(), ex)
+    cls = mods["synth"].cell_classes(N, seed=4, minority_fraction=0.05)
+    assert (ex[cls == 1] == 1).mean() > 0.95 and (ex[cls == 0] == 1).mean() < 0.01
+    g.close()
