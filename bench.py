@@ -1,0 +1,220 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: full EM iterations (compute_new_excluded, main.rs:308-347) over a synthetic
+variant x cell matrix resident in HBM.
+
+  python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run, one rank per GPU)
+
+A step = one EM iteration over the whole matrix: alpha/beta update, per-cell log-likelihood pass (with the
+reference's expected-log-pmf column), exact median/quartiles over all cells, exclusion flags, per-locus
+statistics pass, locus filter.  Cells are sharded across ranks (strong scaling: the matrix is fixed, BASELINE
+cfg4 = 1M cells x 200k loci at 1%); the two exchanges per iteration are all-reduces over RCCL.
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (cells, loci, density)  — BASELINE.json configs
+    "cfg1": (1_000, 2_000, 0.10),
+    "cfg2": (50_000, 50_000, 0.01),
+    "cfg3": (200_000, 100_000, 0.01),
+    "cfg4": (1_000_000, 200_000, 0.01),
+}
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (≈6.3 TB/s achievable)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default=os.environ.get("CELLECTOR_BENCH_WORKLOAD", "cfg4"), choices=list(WORKLOADS))
+    ap.add_argument("--seed", type=int, default=4)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-entries", type=float, default=1.5e7,
+                    help="size of the CPU-baseline sample in matrix entries (~1 us/entry/pass on one core)")
+    ap.add_argument("--no-expected", action="store_true",
+                    help="skip the expected_log_likelihood diagnostic column (NOT the reference-equivalent step)")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    from cellector_amd import Cellector, ffi
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs an MI355X: there is no CPU fallback for the hot path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    N, L_total, density = WORKLOADS[args.workload]
+    per = (N + world - 1) // world
+    cb, ce = min(N, rank * per), min(N, (rank + 1) * per)
+
+    g = Cellector(local_rank, stream=torch.cuda.current_stream().cuda_stream)
+    g.set_option("keep_coo", 0)
+    g.set_option("compute_expected", 0 if args.no_expected else 1)
+    g.set_shard(cb, ce)
+
+    def allreduce(t):
+        if world > 1:
+            dist.all_reduce(t)
+
+    # ---- ingest (untimed setup): device-side generation, pass-1 exchange, CSR/CSC build
+    t_setup = time.time()
+    x_pass1 = torch.zeros(5 * L_total, dtype=torch.float64, device=dev)
+    g.bind_exchange_buffer(ffi.XCHG_PASS1, x_pass1.data_ptr(), x_pass1.numel())
+    g.ingest_synthetic(L_total, N, density, seed=args.seed, minority_fraction=0.05, doublet_fraction=0.0)
+    allreduce(x_pass1)
+    g.ingest_finish(4, 4)
+    dm = g.dims()
+    L = dm.loci_used
+    x_norm = torch.zeros(N, dtype=torch.float64, device=dev)
+    x_locus = torch.zeros(5 * L + 8, dtype=torch.float64, device=dev)
+    g.bind_exchange_buffer(ffi.XCHG_NORM, x_norm.data_ptr(), x_norm.numel())
+    g.bind_exchange_buffer(ffi.XCHG_LOCUS, x_locus.data_ptr(), x_locus.numel())
+    torch.cuda.synchronize()
+    t_setup = time.time() - t_setup
+
+    nnz_local = dm.nnz_used
+    nnz_t = torch.tensor([float(nnz_local)], dtype=torch.float64, device=dev)
+    allreduce(nnz_t)
+    nnz_total = int(nnz_t.item())
+
+    def step():
+        g.em_begin()
+        allreduce(x_norm)
+        g.em_threshold(5.0)
+        allreduce(x_locus)
+        return g.em_finish()
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    g.set_option("timing", 1)
+    g.reset_timing()
+    fence()
+    t0 = time.perf_counter()
+    last = None
+    for _ in range(args.steps):
+        last = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    g.set_option("timing", 0)
+    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    elapsed = float(el.item())
+    ms_per_step = elapsed / args.steps * 1e3
+
+    # ---- per-kernel durations (HIP events on the launch stream, recorded inside the timed region)
+    ll_ms, ll_n = g.kernel_time(ffi.K_CELL_LL)
+    lo_ms, lo_n = g.kernel_time(ffi.K_LOCUS_STATS)
+    se_ms, se_n = g.kernel_time(ffi.K_SELECT)
+    ll_avg = ll_ms / max(ll_n, 1)
+    n_loc = ce - cb
+    # algorithmic bytes of one launch of the cell pass on this rank:
+    #   8 B/entry (u32 locus + u16 alt + u16 ref) + u64 row pointers + f64 LL, u32 loci-used out + alpha,beta once
+    b_pass = nnz_local * 8 + (n_loc + 1) * 8 + n_loc * 12 + L * 16
+    achieved = b_pass / (ll_avg * 1e-3) / 1e9 if ll_avg > 0 else 0.0
+
+    out = None
+    if rank == 0:
+        traffic = None
+        tr_path = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tr_path):
+            try:
+                tr = json.load(open(tr_path))
+                key = f"{args.workload}:n{world}"
+                if key in tr:
+                    traffic = tr[key]["hbm_bytes_per_launch"]
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "cell x locus log-likelihood evals/sec over full EM iterations (EM iters/sec in em_iters_per_s)",
+            "value": nnz_total / (elapsed / args.steps),
+            "unit": "evals/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {N} cells x {L_total} loci, density {density}, seed {args.seed}, "
+                                   "5% minority; cells sharded contiguously across ranks",
+                       "loci_used": int(L), "nnz_used": nnz_total,
+                       "step": "one EM iteration = alpha/beta + cell LL pass"
+                               + ("" if args.no_expected else " (+expected-log-pmf)")
+                               + " + exact quartiles + flags + locus pass + locus filter",
+                       "parallelism": f"cells/{world}" if world > 1 else "1 gpu"},
+            "em_iters_per_s": args.steps / elapsed,
+            "dense_cells_x_loci_per_s": float(N) * float(L) / (elapsed / args.steps),
+            "kernels_ms": {"cell_ll": ll_avg, "locus_stats": lo_ms / max(lo_n, 1), "select": se_ms / max(se_n, 1)},
+            "ll_pass_evals_per_s": nnz_local * world / (ll_avg * 1e-3) if ll_avg > 0 else None,
+            "roofline": {"bound": "hbm", "kernel": "k_cell_ll", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": int(b_pass), "launch_ms": ll_avg},
+            "setup_s": t_setup,
+            "last_iteration": {"n_excluded": int(last.n_excluded), "threshold": last.threshold,
+                               "any_change": int(last.any_change)},
+        }
+
+    # ---- CPU baseline: the oracle (port of the reference's single-threaded path) on a bounded cell sample
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import binding as ob
+        avg_row = max(1.0, nnz_local / max(n_loc, 1))
+        n_sample = int(max(1, min(n_loc, args.cpu_sample_entries / avg_row)))
+        rp, ent = g.csr_rows(0, n_sample)
+        lc = g.locus_counts()
+        o = ob.Oracle.from_csr(L, rp, ent, lc)
+        t1 = time.perf_counter()
+        o.em_iteration(5.0)
+        cpu_s = time.perf_counter() - t1
+        out["cpu_baseline"] = {
+            "value": float(len(ent)) / cpu_s, "unit": "evals/s", "cores": 1, "kind": "port",
+            "sample": f"first {n_sample} cells ({len(ent)} entries) of the same matrix with the full matrix's "
+                      f"alpha/beta, one EM iteration of the single-threaded C oracle in {cpu_s:.1f} s",
+            "host_cpus": os.cpu_count(),
+        }
+        out["gpu_over_cpu_1core"] = out["value"] / out["cpu_baseline"]["value"]
+        o.close()
+    elif rank == 0:
+        out["cpu_baseline"] = None
+
+    if rank == 0:
+        print(json.dumps(out))
+    g.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
