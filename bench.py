@@ -39,6 +39,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-entries", type=float, default=1.5e7,
                     help="size of the CPU-baseline sample in matrix entries (~1 us/entry/pass on one core)")
+    ap.add_argument("--engine", type=int, default=2, choices=[1, 2],
+                    help="2 = table-driven tiled passes (default), 1 = CSR/CSC kernels evaluating every entry")
     ap.add_argument("--no-expected", action="store_true",
                     help="skip the expected_log_likelihood diagnostic column (NOT the reference-equivalent step)")
     return ap.parse_args()
@@ -73,6 +75,7 @@ def main():
 
     g = Cellector(local_rank, stream=torch.cuda.current_stream().cuda_stream)
     g.set_option("keep_coo", 0)
+    g.set_option("engine", args.engine)
     g.set_option("compute_expected", 0 if args.no_expected else 1)
     g.set_shard(cb, ce)
 
@@ -136,12 +139,20 @@ def main():
     ll_ms, ll_n = g.kernel_time(ffi.K_CELL_LL)
     lo_ms, lo_n = g.kernel_time(ffi.K_LOCUS_STATS)
     se_ms, se_n = g.kernel_time(ffi.K_SELECT)
+    ti_ms, ti_n = g.kernel_time(ffi.K_TILE_LL)
     ll_avg = ll_ms / max(ll_n, 1)
     n_loc = ce - cb
-    # algorithmic bytes of one launch of the cell pass on this rank:
-    #   8 B/entry (u32 locus + u16 alt + u16 ref) + u64 row pointers + f64 LL, u32 loci-used out + alpha,beta once
-    b_pass = nnz_local * 8 + (n_loc + 1) * 8 + n_loc * 12 + L * 16
-    achieved = b_pass / (ll_avg * 1e-3) / 1e9 if ll_avg > 0 else 0.0
+    info = g.engine_info()
+    # Dominant kernel and the entries ONE launch of it processes on this rank:
+    #   engine 2: k_tile_ll, the regular entries (1 <= alt+ref <= 3); engine 1: k_cell_ll, all entries.
+    # Algorithmic bytes: 8 B/entry (u32 locus + u16 alt + u16 ref) + u64 row pointers
+    #   + f64 LL and u32 loci-used out per cell + alpha,beta read once per locus.
+    if args.engine == 2:
+        dom_kernel, dom_ms, dom_units = "k_tile_ll", ti_ms / max(ti_n, 1), info.nnz_regular
+    else:
+        dom_kernel, dom_ms, dom_units = "k_cell_ll", ll_avg, nnz_local
+    b_pass = dom_units * 8 + (n_loc + 1) * 8 + n_loc * 12 + L * 16
+    achieved = b_pass / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
 
     out = None
     if rank == 0:
@@ -150,7 +161,7 @@ def main():
         if os.path.exists(tr_path):
             try:
                 tr = json.load(open(tr_path))
-                key = f"{args.workload}:n{world}"
+                key = f"{args.workload}:n{world}:engine{args.engine}"
                 if key in tr:
                     traffic = tr[key]["hbm_bytes_per_launch"]
             except Exception:
@@ -177,11 +188,15 @@ def main():
                        "parallelism": f"cells/{world}" if world > 1 else "1 gpu"},
             "em_iters_per_s": args.steps / elapsed,
             "dense_cells_x_loci_per_s": float(N) * float(L) / (elapsed / args.steps),
-            "kernels_ms": {"cell_ll": ll_avg, "locus_stats": lo_ms / max(lo_n, 1), "select": se_ms / max(se_n, 1)},
+            "kernels_ms": {"cell_pass": ll_avg, "tile_ll": ti_ms / max(ti_n, 1), "locus_pass": lo_ms / max(lo_n, 1),
+                           "select": se_ms / max(se_n, 1)},
             "ll_pass_evals_per_s": nnz_local * world / (ll_avg * 1e-3) if ll_avg > 0 else None,
-            "roofline": {"bound": "hbm", "kernel": "k_cell_ll", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": dom_kernel, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": int(b_pass), "launch_ms": ll_avg},
+                         "algorithmic_bytes_per_launch": int(b_pass), "launch_ms": dom_ms,
+                         "entries_per_launch": int(dom_units)},
+            "engine": {"engine": args.engine, "nnz_regular": int(info.nnz_regular),
+                       "nnz_overflow": int(info.nnz_overflow), "tile_bytes": int(info.tile_bytes)},
             "setup_s": t_setup,
             "last_iteration": {"n_excluded": int(last.n_excluded), "threshold": last.threshold,
                                "any_change": int(last.any_change)},

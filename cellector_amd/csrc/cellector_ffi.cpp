@@ -63,6 +63,7 @@ static void free_matrix(cellector_ctx *c)
     dev_free(c->ab); dev_free(c->ab6); dev_free(c->mask); dev_free(c->mask_next);
     dev_free(c->flags); dev_free(c->flags_new); dev_free(c->ll); dev_free(c->ell); dev_free(c->nloci);
     dev_free(c->post);
+    tiled_free(c);
     if (c->own_pass1) dev_free(c->x_pass1);
     if (c->own_norm) dev_free(c->x_norm);
     if (c->own_locus) dev_free(c->x_locus);
@@ -141,6 +142,16 @@ cellector_status cellector_set_option(cellector_ctx *c, const char *key, int64_t
     if (!strcmp(key, "compute_expected")) c->compute_expected = v != 0;
     else if (!strcmp(key, "timing")) c->timing = v != 0;
     else if (!strcmp(key, "keep_coo")) c->keep_coo = v != 0;
+    else if (!strcmp(key, "engine")) {
+        if (v != 1 && v != 2) return ctx_fail(c, CELLECTOR_EINVAL, "engine must be 1 (CSR/CSC kernels) or 2 (tiled)");
+        if (c->em_phase != 0) return ctx_fail(c, CELLECTOR_EINVAL, "cannot switch engine inside an iteration");
+        if (v == 2 && c->state == cellector_ctx::ST_READY && !c->tiled_ready) {
+            HIPCHK(c, hipSetDevice(c->device));
+            if (c->n_masked_loci) return ctx_fail(c, CELLECTOR_EINVAL, "switch to engine 2 before any locus is masked");
+            CHK(tiled_build(c));
+        }
+        c->engine = (int)v;
+    }
     else return ctx_fail(c, CELLECTOR_EINVAL, "unknown option '%s'", key);
     return CELLECTOR_OK;
 }
@@ -249,6 +260,7 @@ cellector_status cellector_ingest_finish(cellector_ctx *c, uint64_t min_alt, uin
     HIPCHK(c, hipMemsetAsync(c->x_norm, 0, (need_norm ? need_norm : 1) * 8, c->stream));
     HIPCHK(c, hipMemsetAsync(c->x_locus, 0, need_locus * 8, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->engine == 2) CHK(tiled_build(c));
     c->state = cellector_ctx::ST_READY;
     c->em_phase = 0; c->iteration = 0; c->have_iter = false; c->n_excluded_global = 0;
     return CELLECTOR_OK;
@@ -393,7 +405,8 @@ cellector_status cellector_em_begin(cellector_ctx *c)
     CHK(launch_alpha_beta(c));
     if (c->nloc != c->total_cells)  // other shards' slices must be zero before the sum-exchange
         HIPCHK(c, hipMemsetAsync(c->x_norm, 0, c->total_cells * 8, c->stream));
-    CHK(launch_cell_ll(c, c->ab, c->x_norm + c->cell_begin));
+    if (c->engine == 2) CHK(tiled_cell_pass(c, c->ab, c->x_norm + c->cell_begin));
+    else CHK(launch_cell_ll(c, c->ab, c->x_norm + c->cell_begin));
     c->em_phase = 1;
     return CELLECTOR_OK;
 }
@@ -428,7 +441,8 @@ cellector_status cellector_em_threshold(cellector_ctx *c, double iqr_multiple)
     c->last_median = median; c->last_iqr = iqr; c->last_thr = thr;
     HIPCHK(c, hipMemsetAsync(c->x_locus + (uint64_t)LB_PLANES * c->L, 0, LC_COUNTERS * 8, c->stream));
     CHK(launch_flag(c, thr));
-    CHK(launch_locus_stats(c));
+    if (c->engine == 2) CHK(tiled_locus_pass(c));
+    else CHK(launch_locus_stats(c));
     c->em_phase = 2;
     return CELLECTOR_OK;
 }
@@ -446,6 +460,10 @@ cellector_status cellector_em_finish(cellector_ctx *c, cellector_iter_summary *o
     HIPCHK(c, hipMemcpyAsync(cnt, c->x_locus + (uint64_t)LB_PLANES * c->L, sizeof cnt, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(dc, c->d_counters, sizeof dc, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (dc[0]) {
+        c->n_masked_loci += dc[0];
+        if (c->tiled_ready) CHK(tiled_masked_update(c));
+    }
     std::swap(c->flags, c->flags_new);   // excluded_cells <- new_excluded (main.rs:43)
     std::swap(c->mask, c->mask_next);    // loci_used for the next iteration; mask_next keeps this iteration's
     c->n_excluded_global = (uint64_t)cnt[LC_N_EXCLUDED];
@@ -552,7 +570,9 @@ cellector_status cellector_cell_log_likelihoods(cellector_ctx *c, const double *
     REQUIRE(c, c->em_phase == 0, "iteration in flight");
     SETDEV(c);
     CHK(launch_ab_from_host(c, alpha, beta, mask));
-    CHK(launch_cell_ll(c, c->ab, nullptr));
+    // the tiled engine derives the used-locus count from the ctx's own mask; with a caller mask use the CSR kernel
+    if (c->engine == 2 && !mask && c->n_masked_loci == 0) CHK(tiled_cell_pass(c, c->ab, nullptr));
+    else CHK(launch_cell_ll(c, c->ab, nullptr));
     const size_t b = c->nloc * 8;
     if (ll) CHK(d2h(c, ll, c->ll, b));
     if (ell) CHK(d2h(c, ell, c->ell, b));
@@ -574,7 +594,8 @@ cellector_status cellector_posteriors(cellector_ctx *c, double *posterior, doubl
     const double mf = std::fmax(mf0, 0.01);                               // main.rs:250
     const double lp_dbl = std::log(N / 1000.0 / 100.0 * std::fmax(mf, 0.1));  // main.rs:259
     const double lp_min = std::log(mf), lp_maj = std::log(1.0 - mf);      // main.rs:264-265
-    CHK(launch_posteriors(c, mf0, lp_min, lp_maj, lp_dbl));
+    if (c->engine == 2) CHK(tiled_posteriors(c, mf0, lp_min, lp_maj, lp_dbl));
+    else CHK(launch_posteriors(c, mf0, lp_min, lp_maj, lp_dbl));
     const size_t b = c->nloc * 8;
     if (posterior) CHK(d2h(c, posterior, c->post, b));
     if (doublet) CHK(d2h(c, doublet, c->post + c->nloc, b));
@@ -604,6 +625,29 @@ cellector_status cellector_final_allele_tallies(cellector_ctx *c, uint64_t *alt_
     if (ref_min) memcpy(ref_min, h.data() + TL, TL * 8);
     if (alt_maj) memcpy(alt_maj, h.data() + 2 * TL, TL * 8);
     if (ref_maj) memcpy(ref_maj, h.data() + 3 * TL, TL * 8);
+    return CELLECTOR_OK;
+}
+
+cellector_status cellector_engine_info(const cellector_ctx *c, cellector_engine_info_t *o)
+{
+    if (!c || !o) return CELLECTOR_EINVAL;
+    memset(o, 0, sizeof *o);
+    o->engine = (uint64_t)c->engine;
+    if (c->tiled_ready) {
+        o->nnz_regular = c->nnz - c->ovf_n;
+        o->nnz_overflow = c->ovf_n;
+        o->cell_blocks = c->t_nb; o->locus_chunks = c->t_nj; o->chunk_groups = c->t_groups;
+        uint64_t elems = 0;
+        cellector_status s = CELLECTOR_OK;
+        {
+            hipError_t e = hipSetDevice(c->device);
+            if (e == hipSuccess)
+                e = hipMemcpy(&elems, c->tile_ptr + (uint64_t)c->t_nb * c->t_nj, 8, hipMemcpyDeviceToHost);
+            if (e != hipSuccess) s = ctx_fail(c, CELLECTOR_EDEVICE, "engine_info: %s", hipGetErrorString(e));
+        }
+        CHK(s);
+        o->tile_bytes = elems * 2;
+    }
     return CELLECTOR_OK;
 }
 

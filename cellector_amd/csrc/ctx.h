@@ -82,6 +82,29 @@ struct cellector_ctx {
     bool own_pass1 = true, own_norm = true, own_locus = true;
     uint64_t n_pass1 = 0, n_norm = 0, n_locus = 0;
 
+    // ---- engine v2: table-driven tiled layout (kernels_tiled.hip) ----
+    int engine = 2;                  // 1 = v1 CSR/CSC kernels, 2 = tiled (default)
+    bool tiled_ready = false;
+    uint32_t t_nb = 0, t_nj = 0, t_groups = 0, t_cpg = 0;  // cell blocks, locus chunks, chunk groups, chunks/group
+    uint64_t t_npad = 0;             // nb * T_BC
+    uint64_t *tile_ptr = nullptr;    // [nb*nj+1] offsets into tiles, in u16 elements (multiples of 8)
+    uint16_t *tiles = nullptr;       // per tile: [T_BC counts][entries code<<9|locus_in_chunk]
+    uint64_t *ovf_ptr = nullptr, *ovf_ent = nullptr;    // overflow CSR (n == 0 or n > 3), packed like csr_ent
+    uint64_t ovf_n = 0;
+    uint32_t *ovf_perm = nullptr;    // [ovf_n] by-cell position -> by-locus position
+    double *ovf_tab = nullptr;       // [L][64] per-locus cumulative-log / expected tables for overflow entries
+    double2 *ovf_val = nullptr;      // [3][ovf_n] (log-pmf, expected term) of overflow entries, by-locus order
+    uint64_t *c4_ptr = nullptr;      // [L+1] compact CSC of regular entries
+    uint32_t *c4_ent = nullptr;      // cell_local | code << 28
+    uint64_t *ovc_ptr = nullptr, *ovc_ent = nullptr;    // overflow CSC, packed like csc_ent
+    uint32_t *hist_all = nullptr;    // [L][9] regular entries per code
+    double *tab = nullptr;           // [3][nj][12][512] log-pmf / expected tables (set 0: EM pass; 0..2: posterior)
+    double *part = nullptr;          // [3][2][groups][npad] per-group partial sums (ll, ell)
+    double2 *ab3 = nullptr;          // [3][L] posterior alpha/beta sets as double2
+    uint32_t *masked_cnt = nullptr;  // [nloc] entries of the cell at masked loci
+    uint32_t *flag_bits = nullptr;   // [ceil(nloc/32)] new exclusion set as a bitmask
+    uint64_t n_masked_loci = 0;
+
     // order-statistic workspace
     uint32_t *sel_hist = nullptr;   // [SEL_T][256]
     uint64_t *sel_state = nullptr;  // [SEL_T][2] prefix, remaining rank
@@ -162,6 +185,13 @@ cellector_status synth_generate(cellector_ctx *c, double density, uint64_t seed,
 cellector_status dev_exclusive_scan_u64(cellector_ctx *c, uint64_t *data, uint64_t n, uint64_t *total_out_host);
 cellector_status dev_sort_pairs_u32_u64(cellector_ctx *c, uint32_t *keys_in, uint32_t *keys_out,
                                         uint64_t *vals_in, uint64_t *vals_out, uint64_t n, int end_bit);
+// engine v2 (kernels_tiled.hip)
+cellector_status tiled_build(cellector_ctx *c);
+void tiled_free(cellector_ctx *c);
+cellector_status tiled_cell_pass(cellector_ctx *c, const double2 *ab, double *norm_out);
+cellector_status tiled_locus_pass(cellector_ctx *c);
+cellector_status tiled_masked_update(cellector_ctx *c);
+cellector_status tiled_posteriors(cellector_ctx *c, double mf0, double lp_min, double lp_maj, double lp_dbl);
 // host mtx reader (mtx_reader.cpp)
 struct HostCoo {
     uint64_t total_loci = 0, total_cells = 0;

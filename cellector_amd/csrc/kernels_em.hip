@@ -86,20 +86,27 @@ __global__ __launch_bounds__(BLOCK) void k_cell_ll(uint64_t n_rows, const uint64
 // new_excluded = {i : norm_i < threshold} (main.rs:330-332) and the symmetric-difference counts
 // (main.rs:333-334) accumulated as f64 into the LOCUS exchange buffer's counter slots.
 // ---------------------------------------------------------------------------------------------------
-__global__ void k_flag(uint64_t n, const double *__restrict__ norm, double thr,
-                       const uint8_t *__restrict__ old_flags, uint8_t *__restrict__ new_flags,
-                       double *__restrict__ counters)
+__global__ __launch_bounds__(256) void k_flag(uint64_t n, const double *__restrict__ norm, double thr,
+                                              const uint8_t *__restrict__ old_flags, uint8_t *__restrict__ new_flags,
+                                              double *__restrict__ counters)
 {
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    bool in = i < n;
-    bool nf = in && (norm[i] < thr);
-    bool of = in && old_flags[i];
-    if (in) new_flags[i] = nf ? 1 : 0;
-    unsigned long long b_new = __ballot(nf && !of), b_res = __ballot(of && !nf), b_exc = __ballot(nf);
+    uint32_t c_new = 0, c_res = 0, c_exc = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const bool nf = norm[i] < thr;
+        const bool of = old_flags[i] != 0;
+        new_flags[i] = nf ? 1 : 0;
+        c_new += (nf && !of) ? 1u : 0u;
+        c_res += (of && !nf) ? 1u : 0u;
+        c_exc += nf ? 1u : 0u;
+    }
+    // one f64 atomic per wave and counter (integers: exact and order independent)
+    c_new = wave_sum_u32(c_new);
+    c_res = wave_sum_u32(c_res);
+    c_exc = wave_sum_u32(c_exc);
     if ((threadIdx.x & 63) == 0) {
-        if (b_new) atomicAdd(&counters[LC_N_NEW], (double)__popcll(b_new));
-        if (b_res) atomicAdd(&counters[LC_N_RESCUED], (double)__popcll(b_res));
-        if (b_exc) atomicAdd(&counters[LC_N_EXCLUDED], (double)__popcll(b_exc));
+        if (c_new) atomicAdd(&counters[LC_N_NEW], (double)c_new);
+        if (c_res) atomicAdd(&counters[LC_N_RESCUED], (double)c_res);
+        if (c_exc) atomicAdd(&counters[LC_N_EXCLUDED], (double)c_exc);
     }
 }
 
@@ -316,7 +323,7 @@ cellector_status launch_cell_ll(cellector_ctx *c, const double2 *ab, double *nor
 cellector_status launch_flag(cellector_ctx *c, double thr)
 {
     if (c->nloc == 0) return CELLECTOR_OK;
-    hipLaunchKernelGGL(k_flag, dim3(grid_for(c->nloc, 256)), dim3(256), 0, c->stream, c->nloc,
+    hipLaunchKernelGGL(k_flag, dim3(grid_for(c->nloc, 256 * 16, 1024)), dim3(256), 0, c->stream, c->nloc,
                        c->x_norm + c->cell_begin, thr, c->flags, c->flags_new, c->x_locus + LB_PLANES * c->L);
     HIPCHK(c, hipGetLastError());
     return CELLECTOR_OK;

@@ -1,0 +1,916 @@
+// Engine v2: table-driven passes over a tiled 16-bit matrix layout (gfx950, wave64).
+//
+// Observation: under one (alpha_l, beta_l) the log-pmf of an entry depends only on (alt, ref), and vartrix counts
+// are tiny (n = alt+ref <= 3 for ~97 % of entries).  So per EM iteration and locus we tabulate the 9 log-pmfs of
+// n = 1..3 and the 3 expected terms ("tables", 12 f64 per locus) and the matrix passes become pure table lookups:
+//
+//   cell pass   (get_cell_log_likelihoods, main.rs:541-591): the matrix is cut into (1024-cell block x 512-locus
+//               chunk) tiles; a tile is [1024 u16 per-cell counts][u16 entries = code<<9 | locus_in_chunk], cells in
+//               order, loci ascending inside a cell.  A 512-thread workgroup owns one cell block and walks a group
+//               of chunks: stage the chunk's table (48 KB) and the tile in LDS, then every lane walks the segments of
+//               its own two cells and accumulates in registers.  No transcendental, no atomics, ~2.4 B of HBM
+//               traffic per entry, and each cell's sum runs in ascending-locus order like the reference's.
+//   locus pass  (get_locus_log_likelihoods, main.rs:368-420): compact CSC of u32 entries (cell | code<<28); the new
+//               exclusion set is a bitmask staged in LDS; a wave per locus counts minority entries per code with
+//               ballots; contributions are count x table value; the majority side is (static histogram - minority).
+//   overflow    entries with n == 0 or n > 3 (~3 %) live in a small CSR/CSC in the v1 packed format and take the
+//               v1 arithmetic (device_math.h); the finalize kernels add them in a fixed order.
+#include "ctx.h"
+#include "device_math.h"
+
+#define T_K 3
+#define T_NCODE 9
+#define T_W 12
+#define T_BL 512
+#define T_BLOG 9
+#define T_BC 1024       // cells per block == threads per workgroup: one lane per cell
+#define T_THREADS 1024
+#ifndef T_SB
+#define T_SB 2          // cell blocks per workgroup (they share one staged table)
+#endif
+#define T_CAP 6144      // entries of one tile staged per window (12 KB)
+#define T_GROUPS 8
+#define T_HDR 2056      // tile header in u16 units: (T_BC + 1) u32 exclusive offsets, padded to 16 bytes
+#define T_IDX_MASK 0x1fffu  // entry bits 0..12 = code*512 + locus_in_chunk (the table index); bits 13..14 = n-1
+
+__device__ __constant__ uint8_t T_A_OF[T_NCODE] = {1, 0, 2, 1, 0, 3, 2, 1, 0};
+__device__ __constant__ uint8_t T_R_OF[T_NCODE] = {0, 1, 0, 1, 2, 0, 1, 2, 3};
+
+__device__ __forceinline__ bool ent_regular(uint64_t e)
+{
+    const uint32_t n = ENT_ALT(e) + ENT_REF(e);
+    return n >= 1u && n <= (uint32_t)T_K;
+}
+__device__ __forceinline__ uint32_t ent_code(uint64_t e)
+{
+    const uint32_t r = ENT_REF(e), n = ENT_ALT(e) + r;
+    return n * (n + 1u) / 2u - 1u + r;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// tables: tab[j][w][loc], w = 0..8 log-pmf of code w, w = 9..11 expected term of n = w-8; zero rows for masked
+// loci (alpha < 0) and for the padding beyond L.
+// ---------------------------------------------------------------------------------------------------------
+__global__ void k_build_tables(uint64_t L, uint32_t nj, const double2 *__restrict__ ab, const double *__restrict__ lf,
+                               double *__restrict__ tab, int expected)
+{
+    const uint64_t l = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= (uint64_t)nj * T_BL) return;
+    double *row = tab + (l >> T_BLOG) * (uint64_t)(T_W * T_BL) + (l & (T_BL - 1));
+    double2 p = make_double2(-1.0, -1.0);
+    if (l < L) p = ab[l];
+    const bool live = p.x >= 0.0;
+#pragma unroll
+    for (int w = 0; w < T_NCODE; w++)
+        row[w * T_BL] = live ? dm_log_bb_pmf(lf, p.x, p.y, T_A_OF[w], T_R_OF[w]) : 0.0;
+#pragma unroll
+    for (int n = 1; n <= T_K; n++)
+        row[(T_NCODE + n - 1) * T_BL] = (live && expected) ? dm_expected_log_pmf(lf, p.x, p.y, (uint32_t)n) : 0.0;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// cell pass over the tiles
+// ---------------------------------------------------------------------------------------------------------
+template <bool EXPECTED>
+__global__ __launch_bounds__(T_THREADS, 8) void k_tile_ll(uint32_t nb, uint32_t nj, uint32_t cpg,
+                                                          const uint64_t *__restrict__ tile_ptr,
+                                                          const uint16_t *__restrict__ tiles,
+                                                          const double *__restrict__ tab, uint64_t npad,
+                                                          double *__restrict__ part_ll, double *__restrict__ part_ell)
+{
+    __shared__ double s_tab[T_W * T_BL];      // 48 KB: this chunk's table, [w][locus]
+    __shared__ uint4 s_ent[T_SB][T_CAP / 8];  // staged tile entries (first window of each cell block)
+    const uint32_t tid = threadIdx.x;
+    const uint32_t b0 = blockIdx.x * T_SB, g = blockIdx.y;
+    const uint32_t j0 = g * cpg, j1 = min(nj, j0 + cpg);
+    double ll[T_SB], el[T_SB];
+#pragma unroll
+    for (int s = 0; s < T_SB; s++) ll[s] = el[s] = 0.0;
+
+    // registers that carry the NEXT chunk's data while the current one is being consumed
+    static_assert(T_W * T_BL / 2 / T_THREADS == 3, "table prefetch registers are written out by hand");
+    double2 p_tab0, p_tab1, p_tab2;
+    uint32_t p_beg[T_SB], p_end[T_SB], p_tot[T_SB];
+    uint4 p_ent[T_SB];
+#define TILE_PREFETCH(J)                                                                                        \
+    do {                                                                                                        \
+        const double2 *src__ = reinterpret_cast<const double2 *>(tab + (uint64_t)(J) * (T_W * T_BL));           \
+        p_tab0 = src__[tid];                                                                                    \
+        p_tab1 = src__[tid + T_THREADS];                                                                        \
+        p_tab2 = src__[tid + 2 * T_THREADS];                                                                    \
+        _Pragma("unroll") for (int s = 0; s < T_SB; s++) {                                                     \
+            p_beg[s] = p_end[s] = p_tot[s] = 0;                                                                 \
+            p_ent[s] = make_uint4(0, 0, 0, 0);                                                                  \
+            if (b0 + s < nb) {                                                                                  \
+                const uint16_t *tp__ = tiles + tile_ptr[(uint64_t)(b0 + s) * nj + (J)];                         \
+                const uint32_t *hd__ = reinterpret_cast<const uint32_t *>(tp__);                                \
+                p_beg[s] = hd__[tid];                                                                           \
+                p_end[s] = hd__[tid + 1];                                                                       \
+                p_tot[s] = hd__[T_BC];                                                                          \
+                /* first window; reading past a short tile stays inside the allocation (next tile / tail pad) */ \
+                if (tid < T_CAP / 8) p_ent[s] = reinterpret_cast<const uint4 *>(tp__ + T_HDR)[tid];             \
+            }                                                                                                   \
+        }                                                                                                       \
+    } while (0)
+
+    if (j0 < j1) TILE_PREFETCH(j0);
+    for (uint32_t j = j0; j < j1; j++) {
+        __syncthreads();  // everybody is done with the previous chunk's LDS contents
+        {
+            double2 *dst = reinterpret_cast<double2 *>(s_tab);
+            dst[tid] = p_tab0;
+            dst[tid + T_THREADS] = p_tab1;
+            dst[tid + 2 * T_THREADS] = p_tab2;
+#pragma unroll
+            for (int s = 0; s < T_SB; s++)
+                if (tid < T_CAP / 8) s_ent[s][tid] = p_ent[s];
+        }
+        uint32_t my_s[T_SB], my_e[T_SB], total[T_SB];
+#pragma unroll
+        for (int s = 0; s < T_SB; s++) { my_s[s] = p_beg[s]; my_e[s] = p_end[s]; total[s] = p_tot[s]; }
+        __syncthreads();
+        if (j + 1 < j1) TILE_PREFETCH(j + 1);  // in flight during the compute below
+#pragma unroll
+        for (int s = 0; s < T_SB; s++) {
+            const uint16_t *se = reinterpret_cast<const uint16_t *>(s_ent[s]);
+            double a_ll = ll[s], a_el = el[s];
+            for (uint32_t w0 = 0; w0 < total[s]; w0 += T_CAP) {  // total is uniform over the workgroup
+                const uint32_t n_in = min((uint32_t)T_CAP, total[s] - w0);
+                if (w0) {  // a tile larger than one window (dense data): stage the next window synchronously
+                    const uint16_t *tp = tiles + tile_ptr[(uint64_t)(b0 + s) * nj + j];
+                    const uint4 *ep = reinterpret_cast<const uint4 *>(tp + T_HDR);
+                    __syncthreads();
+                    for (uint32_t i = tid; i < ((n_in + 7u) >> 3); i += T_THREADS) s_ent[s][i] = ep[(w0 >> 3) + i];
+                    __syncthreads();
+                }
+                const uint32_t klo = max(my_s[s], w0), khi = min(my_e[s], w0 + n_in);
+                for (uint32_t k = klo; k < khi; ++k) {
+                    const uint32_t e = se[k - w0];
+                    a_ll += s_tab[e & T_IDX_MASK];
+                    if (EXPECTED) a_el += s_tab[((e >> 13) + T_NCODE) * T_BL + (e & (T_BL - 1))];
+                }
+            }
+            ll[s] = a_ll;
+            el[s] = a_el;
+        }
+    }
+#undef TILE_PREFETCH
+#pragma unroll
+    for (int s = 0; s < T_SB; s++) {
+        if (b0 + s < nb) {
+            const uint64_t c = (uint64_t)g * npad + (uint64_t)(b0 + s) * T_BC + tid;
+            part_ll[c] = ll[s];
+            if (EXPECTED) part_ell[c] = el[s];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// overflow entries (n == 0 or n > 3).  Their log-pmf / expected term are evaluated once per pass in LOCUS-major
+// order (k_ovf_values: alpha/beta wave-uniform, so ln B-ratios come from per-locus cumulative log tables held in
+// registers and fetched by cross-lane shuffles), stored as double2 per entry, and then only GATHERED: by the cell
+// side through a precomputed permutation (k_ovf_finalize) and by the locus pass directly (k_locus_ovf).
+// ---------------------------------------------------------------------------------------------------------
+#define OV_NT 18  // cumulative tables cover counts 0..17; larger counts take the generic device_math path
+#define OV_NE 17  // expected terms E(n) tabulated for n = 4..17
+
+// rare cases kept out of line so that the common path stays small
+__device__ __noinline__ double ov_slow_log_pmf(const double *lf, double alpha, double beta, uint32_t a, uint32_t r)
+{
+    return dm_log_bb_pmf(lf, alpha, beta, a, r);
+}
+__device__ __noinline__ double ov_slow_expected(const double *lf, double alpha, double beta, uint32_t n)
+{
+    return dm_expected_log_pmf(lf, alpha, beta, n);
+}
+
+// Per-locus overflow table, 64 doubles: [0..17] LA[i] = sum_{m<i} ln(alpha+m), [18..35] LB, [36..53] LAB,
+// [64..77] E(n) for n = 4..17 (ln sum_k pmf(k)^2, stats.rs:8-22).  One thread per locus.
+#define OV_ROW 128
+#define OV_EOFF 64
+__global__ void k_ovf_tables(uint64_t L, const double2 *__restrict__ ab, double *__restrict__ otab)
+{
+    const uint64_t l = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= L) return;
+    double *row = otab + l * OV_ROW;
+    const double2 p = ab[l];
+    if (!(p.x >= 0.0)) {
+        row[0] = -1.0;  // marks a masked locus
+        return;
+    }
+    double la = 0.0, lb = 0.0, lab = 0.0;
+    for (int i = 0; i < OV_NT; i++) {
+        row[i] = la;
+        row[OV_NT + i] = lb;
+        row[2 * OV_NT + i] = lab;
+        la += log(p.x + (double)i);
+        lb += log(p.y + (double)i);
+        lab += log((p.x + p.y) + (double)i);
+    }
+}
+
+// E(n), n = 4..17, one thread per (locus, n): ln sum_k pmf(k)^2 from the cumulative tables written above
+__global__ void k_ovf_tables_e(uint64_t L, const double *__restrict__ lf, double *__restrict__ otab)
+{
+    const uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t l = idx / (OV_NE - 3);
+    if (l >= L) return;
+    const int n = 4 + (int)(idx % (OV_NE - 3));
+    double *row = otab + l * OV_ROW;
+    if (row[0] < 0.0) return;  // masked locus
+    const double labn = row[2 * OV_NT + n];
+    double ssum = 0.0;  // pmf(k) >= 1/(n+1) for the modal k: no underflow of the sum
+    for (int k = 0; k <= n; k++)
+        ssum += exp(2.0 * (dm_ln_choose(lf, (uint32_t)k, (uint32_t)(n - k)) + (row[k] + row[OV_NT + n - k] - labn)));
+    row[OV_EOFF + (n - 4)] = log(ssum);
+}
+
+template <bool EXPECTED>
+__global__ __launch_bounds__(256) void k_ovf_values(uint64_t L, const uint64_t *__restrict__ ovc_ptr,
+                                                    const uint64_t *__restrict__ ovc_ent,
+                                                    const double2 *__restrict__ ab, const double *__restrict__ lf_g,
+                                                    const double *__restrict__ otab, double2 *__restrict__ val)
+{
+    __shared__ double lf[LF_TABLE_N];
+    for (int i = threadIdx.x; i < LF_TABLE_N; i += 256) lf[i] = lf_g[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const uint64_t wave0 = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (uint64_t)gridDim.x * 4;
+    for (uint64_t l = wave0; l < L; l += nwaves) {
+        const uint64_t beg = ovc_ptr[l], end = ovc_ptr[l + 1];
+        if (beg == end) continue;
+        const double2 p = ab[l];
+        if (!(p.x >= 0.0)) {  // masked locus: no PMFData (main.rs:556)
+            for (uint64_t i = beg + lane; i < end; i += 64) val[i] = make_double2(0.0, 0.0);
+            continue;
+        }
+        const double tv = otab[l * OV_ROW + lane];              // cumulative log tables, one value per lane
+        const double tw = otab[l * OV_ROW + OV_EOFF + lane];    // expected terms
+        for (uint64_t i0 = beg; i0 < end; i0 += 64) {
+            const uint64_t i = i0 + lane;
+            const bool in = i < end;
+            const uint64_t en = in ? ovc_ent[i] : 0;
+            const uint32_t a = ENT_ALT(en), r = ENT_REF(en), n = a + r;
+            const bool fast = n < (uint32_t)OV_NT;
+            const double la = __shfl(tv, (int)min(a, (uint32_t)OV_NT - 1), 64);
+            const double lb = __shfl(tv, OV_NT + (int)min(r, (uint32_t)OV_NT - 1), 64);
+            const double lab = __shfl(tv, 2 * OV_NT + (int)min(n, (uint32_t)OV_NT - 1), 64);
+            const double ex = __shfl(tw, (int)(min(max(n, 4u), (uint32_t)OV_NE) - 4u), 64);
+            if (!in) continue;
+            double lp, ee = 0.0;
+            if (n == 0) lp = 0.0;  // quirk Q14: exactly zero
+            else if (fast) lp = dm_ln_choose(lf, a, r) + (la + lb - lab);
+            else lp = ov_slow_log_pmf(lf, p.x, p.y, a, r);
+            if (EXPECTED && n != 0) ee = (n >= 4 && n <= (uint32_t)OV_NE) ? ex : ov_slow_expected(lf, p.x, p.y, n);
+            val[i] = make_double2(lp, ee);
+        }
+    }
+}
+
+// perm[position in the by-cell overflow array] = position in the by-locus overflow array
+__global__ __launch_bounds__(256) void k_ovf_perm(uint64_t L, const uint64_t *__restrict__ ovc_ptr,
+                                                  const uint64_t *__restrict__ ovc_ent,
+                                                  const uint64_t *__restrict__ ovf_ptr,
+                                                  const uint64_t *__restrict__ ovf_ent, uint32_t *__restrict__ perm)
+{
+    const int lane = threadIdx.x & 63;
+    const uint64_t wave0 = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (uint64_t)gridDim.x * 4;
+    for (uint64_t l = wave0; l < L; l += nwaves) {
+        const uint64_t beg = ovc_ptr[l], end = ovc_ptr[l + 1];
+        for (uint64_t i = beg + lane; i < end; i += 64) {
+            const uint32_t cell = ENT_IDX(ovc_ent[i]);
+            uint64_t lo = ovf_ptr[cell], hi = ovf_ptr[cell + 1];
+            while (lo < hi) {
+                const uint64_t mid = (lo + hi) >> 1;
+                if (ENT_IDX(ovf_ent[mid]) < (uint32_t)l) lo = mid + 1; else hi = mid;
+            }
+            // duplicate (locus, cell) lines of a malformed file sit next to each other in both orders
+            uint64_t d = 0;
+            while (i - d > beg && ENT_IDX(ovc_ent[i - d - 1]) == cell) d++;
+            perm[lo + d] = (uint32_t)i;
+        }
+    }
+}
+
+// cell side: gather the overflow values, join the chunk-group partials in one fixed-shape shuffle tree, normalise
+template <bool EXPECTED>
+__global__ __launch_bounds__(256) void k_ovf_finalize(uint64_t n_rows, const uint64_t *__restrict__ ovf_ptr,
+                                                      const uint32_t *__restrict__ perm,
+                                                      const double2 *__restrict__ val, uint32_t groups, uint64_t npad,
+                                                      const double *__restrict__ part_ll,
+                                                      const double *__restrict__ part_ell,
+                                                      const uint64_t *__restrict__ csr_ptr,
+                                                      const uint32_t *__restrict__ masked_cnt, double *__restrict__ ll,
+                                                      double *__restrict__ ell, double *__restrict__ nloci,
+                                                      double *__restrict__ norm_out)
+{
+    const int lane = threadIdx.x & 63;
+    const uint64_t wave0 = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (uint64_t)gridDim.x * 4;
+    for (uint64_t row = wave0; row < n_rows; row += nwaves) {
+        const uint64_t beg = ovf_ptr[row], end = ovf_ptr[row + 1];
+        double s = 0.0, e = 0.0;
+        for (uint64_t i = beg + lane; i < end; i += 64) {
+            const double2 v = val[perm[i]];
+            s += v.x;
+            if (EXPECTED) e += v.y;
+        }
+        if ((uint32_t)lane < groups) {
+            s += part_ll[(uint64_t)lane * npad + row];
+            if (EXPECTED) e += part_ell[(uint64_t)lane * npad + row];
+        }
+        s = wave_sum(s);
+        if (EXPECTED) e = wave_sum(e);
+        if (lane == 0) {
+            const double cnt = (double)((csr_ptr[row + 1] - csr_ptr[row]) - (uint64_t)masked_cnt[row]);
+            ll[row] = s;
+            if (EXPECTED) ell[row] = e;
+            nloci[row] = cnt;
+            if (norm_out) norm_out[row] = cnt > 0.0 ? s / cnt : 0.0;  // main.rs:315-322
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// locus pass over the compact CSC
+// ---------------------------------------------------------------------------------------------------------
+__global__ void k_pack_flag_bits(uint64_t n, const uint8_t *__restrict__ flags, uint32_t *__restrict__ bits)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned long long m = __ballot(i < n && flags[i] != 0);
+    const uint64_t w = i >> 5;
+    if ((threadIdx.x & 31) == 0 && w * 32 < n) bits[w] = (uint32_t)(m >> (threadIdx.x & 32));
+}
+
+#define LS_THREADS 1024
+#define LS_FLUSH 15  // vector iterations between wave reductions: 15*4 = 60 per lane and field, 64*60 < 4096 (12-bit fields)
+template <bool BITS_IN_LDS>
+__global__ __launch_bounds__(LS_THREADS) void k_locus_stats2(uint64_t L, uint32_t nbits_words,
+                                                             const uint64_t *__restrict__ c4_ptr,
+                                                             const uint32_t *__restrict__ c4_ent,
+                                                             const uint32_t *__restrict__ flag_bits,
+                                                             const uint32_t *__restrict__ hist_all,
+                                                             const double *__restrict__ tab,
+                                                             const uint8_t *__restrict__ mask, double *__restrict__ out)
+{
+    extern __shared__ uint32_t s_bits[];
+    if (BITS_IN_LDS) {
+        for (uint32_t i = threadIdx.x; i < nbits_words; i += LS_THREADS) s_bits[i] = flag_bits[i];
+        __syncthreads();
+    }
+    const uint32_t *bits = BITS_IN_LDS ? s_bits : flag_bits;
+    const int lane = threadIdx.x & 63;
+    const uint64_t wave0 = (uint64_t)blockIdx.x * (LS_THREADS / 64) + (threadIdx.x >> 6);
+    const uint64_t nwaves = (uint64_t)gridDim.x * (LS_THREADS / 64);
+    for (uint64_t l = wave0; l < L; l += nwaves) {
+        // columns are padded to whole 16-byte vectors with 0xFFFFFFFF (code 15 = no entry)
+        const uint64_t vbeg = c4_ptr[l] >> 2, nvec = (c4_ptr[l + 1] >> 2) - vbeg;
+        const uint4 *vp = reinterpret_cast<const uint4 *>(c4_ent) + vbeg;
+        uint32_t tot[T_NCODE];  // lane 0: minority entries per code
+#pragma unroll
+        for (int k = 0; k < T_NCODE; k++) tot[k] = 0;
+        uint64_t pa = 0, pb = 0;  // packed 12-bit counters: codes 0..4 in pa, 5..8 in pb
+        uint32_t since = 0;
+        for (uint64_t i0 = 0; i0 < nvec; i0 += 64) {
+            const uint64_t i = i0 + lane;
+            uint4 v = make_uint4(~0u, ~0u, ~0u, ~0u);
+            if (i < nvec) v = vp[i];
+            const uint32_t xs[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const uint32_t x = xs[q], code = x >> 28;
+                const bool valid = code < (uint32_t)T_NCODE;
+                const uint32_t cell = valid ? (x & 0x0fffffffu) : 0u;
+                const uint64_t inc = valid ? (uint64_t)((bits[cell >> 5] >> (cell & 31)) & 1u) : 0ull;
+                if (code < 5u) pa += inc << (12u * code);
+                else pb += inc << (12u * ((code - 5u) & 3u));
+            }
+            if (++since == LS_FLUSH || i0 + 64 >= nvec) {  // wave-uniform
+                const uint64_t sa = wave_sum_u64(pa), sb = wave_sum_u64(pb);
+#pragma unroll
+                for (int k = 0; k < 5; k++) tot[k] += (uint32_t)(sa >> (12 * k)) & 0xfffu;
+#pragma unroll
+                for (int k = 5; k < T_NCODE; k++) tot[k] += (uint32_t)(sb >> (12 * (k - 5))) & 0xfffu;
+                pa = pb = 0;
+                since = 0;
+            }
+        }
+        // lane k < 9 takes code k: minority count (from lane 0), static histogram, table value
+        uint32_t mycnt = 0;
+#pragma unroll
+        for (int k = 0; k < T_NCODE; k++) {
+            const uint32_t t0 = (uint32_t)__shfl((int)tot[k], 0, 64);
+            if (lane == k) mycnt = t0;
+        }
+        const bool live = mask[l] != 0;
+        double cmin = 0.0, cmaj = 0.0;
+        uint32_t nmin = 0, amin = 0, rmin = 0;
+        if (lane < T_NCODE) {
+            const uint32_t all = hist_all[l * T_NCODE + lane];
+            nmin = mycnt;
+            amin = mycnt * T_A_OF[lane];
+            rmin = mycnt * T_R_OF[lane];
+            if (live) {
+                const double t = tab[(l >> T_BLOG) * (uint64_t)(T_W * T_BL) + (uint64_t)lane * T_BL + (l & (T_BL - 1))];
+                cmin = (double)mycnt * t;
+                cmaj = (double)(all - mycnt) * t;
+            }
+        }
+        // fixed-shape sum over the nine codes (lanes 0..8): deterministic
+        cmin = wave_sum(cmin);
+        cmaj = wave_sum(cmaj);
+        nmin = wave_sum_u32(nmin);
+        amin = wave_sum_u32(amin);
+        rmin = wave_sum_u32(rmin);
+        if (lane == 0) {
+            out[LB_CONTRIB_MIN * L + l] = cmin;
+            out[LB_CONTRIB_MAJ * L + l] = cmaj;
+            out[LB_CELLS_MIN * L + l] = live ? (double)nmin : 0.0;
+            out[LB_ALT_MIN * L + l] = (double)amin;
+            out[LB_REF_MIN * L + l] = (double)rmin;
+        }
+    }
+}
+
+// overflow part of the locus pass: stored values, adds into the planes written by k_locus_stats2
+__global__ __launch_bounds__(256) void k_locus_ovf(uint64_t L, const uint64_t *__restrict__ col_ptr,
+                                                   const uint64_t *__restrict__ ent, const double2 *__restrict__ val,
+                                                   const uint8_t *__restrict__ mask, const uint8_t *__restrict__ flags,
+                                                   double *__restrict__ out)
+{
+    const int lane = threadIdx.x & 63;
+    const uint64_t wave0 = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (uint64_t)gridDim.x * 4;
+    for (uint64_t l = wave0; l < L; l += nwaves) {
+        const uint64_t beg = col_ptr[l], end = col_ptr[l + 1];
+        if (end == beg) continue;
+        const bool live = mask[l] != 0;
+        double cmin = 0.0, cmaj = 0.0;
+        uint32_t nmin = 0;
+        uint64_t amin = 0, rmin = 0;
+        for (uint64_t i = beg + lane; i < end; i += 64) {
+            const uint64_t en = ent[i];
+            const bool minority = flags[ENT_IDX(en)] != 0;
+            if (minority) { amin += ENT_ALT(en); rmin += ENT_REF(en); }
+            if (live) {
+                const double lp = val[i].x;
+                if (minority) { cmin += lp; nmin++; } else cmaj += lp;
+            }
+        }
+        cmin = wave_sum(cmin); cmaj = wave_sum(cmaj);
+        nmin = wave_sum_u32(nmin); amin = wave_sum_u64(amin); rmin = wave_sum_u64(rmin);
+        if (lane == 0) {
+            out[LB_CONTRIB_MIN * L + l] += cmin;
+            out[LB_CONTRIB_MAJ * L + l] += cmaj;
+            out[LB_CELLS_MIN * L + l] += (double)nmin;
+            out[LB_ALT_MIN * L + l] += (double)amin;
+            out[LB_REF_MIN * L + l] += (double)rmin;
+        }
+    }
+}
+
+// entries of newly masked loci no longer count as used loci of their cells (main.rs:556,575)
+__global__ __launch_bounds__(256) void k_masked_update(uint64_t L, const uint8_t *__restrict__ mask_old,
+                                                       const uint8_t *__restrict__ mask_new,
+                                                       const uint64_t *__restrict__ c4_ptr,
+                                                       const uint32_t *__restrict__ c4_ent,
+                                                       const uint64_t *__restrict__ ovc_ptr,
+                                                       const uint64_t *__restrict__ ovc_ent,
+                                                       uint32_t *__restrict__ masked_cnt)
+{
+    const int lane = threadIdx.x & 63;
+    const uint64_t wave0 = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (uint64_t)gridDim.x * 4;
+    for (uint64_t l = wave0; l < L; l += nwaves) {
+        if (!(mask_old[l] && !mask_new[l])) continue;
+        for (uint64_t i = c4_ptr[l] + lane; i < c4_ptr[l + 1]; i += 64) {
+            const uint32_t x = c4_ent[i];
+            if ((x >> 28) < (uint32_t)T_NCODE) atomicAdd(&masked_cnt[x & 0x0fffffffu], 1u);
+        }
+        for (uint64_t i = ovc_ptr[l] + lane; i < ovc_ptr[l + 1]; i += 64) atomicAdd(&masked_cnt[ENT_IDX(ovc_ent[i])], 1u);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// posterior phase (calculate_posteriors, main.rs:228-280)
+// ---------------------------------------------------------------------------------------------------------
+__global__ void k_ab_posterior3(uint64_t L, const double *__restrict__ s_alt, const double *__restrict__ s_ref,
+                                const double *__restrict__ alt_min, const double *__restrict__ ref_min, double mf0,
+                                double2 *__restrict__ ab3, double *__restrict__ ab6)
+{
+    const uint64_t l = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= L) return;
+    double a_maj = (s_alt[l] + 1.0) - alt_min[l], b_maj = (s_ref[l] + 1.0) - ref_min[l];          // main.rs:239
+    const double a_min = (s_alt[l] + 1.0) - (s_alt[l] - alt_min[l]);                                // main.rs:241
+    const double b_min = (s_ref[l] + 1.0) - (s_ref[l] - ref_min[l]);
+    const double a_dbl = (a_maj - 1.0) * mf0 + (a_min - 1.0) + 1.0;                                 // main.rs:245
+    const double b_dbl = (b_maj - 1.0) * mf0 + (b_min - 1.0) + 1.0;
+    const double mf = fmax(mf0, 0.01);                                                              // main.rs:250
+    a_maj = (a_maj - 1.0) * mf + 1.0;                                                               // main.rs:252
+    b_maj = (b_maj - 1.0) * mf + 1.0;
+    ab3[l] = make_double2(a_min, b_min);
+    ab3[L + l] = make_double2(a_maj, b_maj);
+    ab3[2 * L + l] = make_double2(a_dbl, b_dbl);
+    double *o = ab6 + 8 * l;
+    o[0] = a_min; o[1] = b_min; o[2] = a_maj; o[3] = b_maj; o[4] = a_dbl; o[5] = b_dbl; o[6] = 0.0; o[7] = 0.0;
+}
+
+__global__ __launch_bounds__(256) void k_posterior_finalize(uint64_t n_rows, const uint64_t *__restrict__ ovf_ptr,
+                                                            const uint32_t *__restrict__ perm,
+                                                            const double2 *__restrict__ val /*[3][ovf_n]*/,
+                                                            uint64_t ovf_n, uint32_t groups, uint64_t npad,
+                                                            const double *__restrict__ part /*[3][2][G][npad]*/,
+                                                            double lp_min, double lp_maj, double lp_dbl,
+                                                            double *__restrict__ post)
+{
+    const int lane = threadIdx.x & 63;
+    const uint64_t wave0 = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (uint64_t)gridDim.x * 4;
+    const uint64_t set_stride = 2ull * groups * npad;
+    for (uint64_t row = wave0; row < n_rows; row += nwaves) {
+        const uint64_t beg = ovf_ptr[row], end = ovf_ptr[row + 1];
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+        for (uint64_t i = beg + lane; i < end; i += 64) {
+            const uint64_t p = perm[i];
+            s0 += val[p].x;
+            s1 += val[ovf_n + p].x;
+            s2 += val[2 * ovf_n + p].x;
+        }
+        if ((uint32_t)lane < groups) {
+            s0 += part[(uint64_t)lane * npad + row];
+            s1 += part[set_stride + (uint64_t)lane * npad + row];
+            s2 += part[2 * set_stride + (uint64_t)lane * npad + row];
+        }
+        s0 = wave_sum(s0); s1 = wave_sum(s1); s2 = wave_sum(s2);
+        if (lane == 0) {
+            const double s_min = s0, s_maj = s1, s_dbl = s2;
+            const double log_num = lp_min + s_min;                       // main.rs:267
+            double log_den = dm_logsumexp(log_num, lp_maj + s_maj);      // main.rs:268
+            const double log_dbl = lp_dbl + s_dbl;                       // main.rs:270
+            log_den = dm_logsumexp(log_den, log_dbl);                    // main.rs:271
+            post[row] = exp(log_num - log_den);
+            post[n_rows + row] = exp(log_dbl - log_den);
+            post[2 * n_rows + row] = s_maj;
+            post[3 * n_rows + row] = s_min;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// build: tiles + overflow CSR from the by-cell CSR; compact CSC + overflow CSC + per-locus code histogram
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t row_lower_bound(const uint64_t *__restrict__ ent, uint64_t lo, uint64_t hi, uint32_t locus)
+{
+    while (lo < hi) {
+        const uint64_t mid = (lo + hi) >> 1;
+        if (ENT_IDX(ent[mid]) < locus) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+// one 1024-thread block per tile, thread = cell of the block.  FILL = false: tile size; FILL = true: write the tile.
+template <bool FILL>
+__global__ __launch_bounds__(T_BC) void k_tile_build(uint64_t nloc, uint32_t nj, uint64_t tile0,
+                                                     const uint64_t *__restrict__ csr_ptr,
+                                                     const uint64_t *__restrict__ csr_ent,
+                                                     uint64_t *__restrict__ tile_elems /*count pass: out; fill: tile_ptr*/,
+                                                     uint16_t *__restrict__ tiles)
+{
+    __shared__ uint32_t s_ws[T_BC / 64];
+    const uint64_t t = tile0 + blockIdx.x;
+    const uint32_t b = (uint32_t)(t / nj), j = (uint32_t)(t % nj);
+    const uint32_t cl = threadIdx.x, lane = cl & 63, wv = cl >> 6;
+    const uint64_t row = (uint64_t)b * T_BC + cl;
+    uint64_t lo = 0, hi = 0;
+    uint32_t reg = 0;
+    if (row < nloc) {
+        const uint64_t beg = csr_ptr[row], end = csr_ptr[row + 1];
+        lo = row_lower_bound(csr_ent, beg, end, j * T_BL);
+        hi = row_lower_bound(csr_ent, lo, end, (j + 1u) * T_BL);
+        for (uint64_t i = lo; i < hi; i++) reg += ent_regular(csr_ent[i]) ? 1u : 0u;
+    }
+    uint32_t inc = reg;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t o = __shfl_up(inc, off, 64);
+        if (lane >= (uint32_t)off) inc += o;
+    }
+    if (lane == 63) s_ws[wv] = inc;
+    __syncthreads();
+    uint32_t woff = 0, total = 0;
+    for (int k = 0; k < T_BC / 64; k++) {
+        const uint32_t v = s_ws[k];
+        if ((uint32_t)k < wv) woff += v;
+        total += v;
+    }
+    if (!FILL) {
+        if (cl == 0) tile_elems[t] = (uint64_t)T_HDR + ((total + 7u) & ~7u);
+        return;
+    }
+    uint16_t *tp = tiles + tile_elems[t];
+    uint32_t *hd = reinterpret_cast<uint32_t *>(tp);
+    hd[cl] = woff + inc - reg;          // exclusive offset of this cell's segment
+    if (cl == 0) hd[T_BC] = total;
+    uint16_t *dst = tp + T_HDR + (woff + inc - reg);
+    for (uint64_t i = lo; i < hi; i++) {
+        const uint64_t e = csr_ent[i];
+        if (ent_regular(e))
+            *dst++ = (uint16_t)(((ENT_ALT(e) + ENT_REF(e) - 1u) << 13) | (ent_code(e) << T_BLOG) | (ENT_IDX(e) - j * T_BL));
+    }
+    // zero the padding so that staged vectors never carry garbage
+    if (cl == 0) {
+        for (uint32_t k = total; k < ((total + 7u) & ~7u); k++) tp[T_HDR + k] = 0;
+        for (uint32_t k = 2 * (T_BC + 1); k < T_HDR; k++) tp[k] = 0;
+    }
+}
+
+// wave per row/column: count entries that are NOT regular (FILL = false) or copy them in order (FILL = true)
+template <bool FILL>
+__global__ __launch_bounds__(256) void k_ovf_build(uint64_t n_rows, const uint64_t *__restrict__ ptr,
+                                                   const uint64_t *__restrict__ ent, uint64_t *__restrict__ optr,
+                                                   uint64_t *__restrict__ oent)
+{
+    const int lane = threadIdx.x & 63;
+    const uint64_t wave0 = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (uint64_t)gridDim.x * 4;
+    for (uint64_t row = wave0; row < n_rows; row += nwaves) {
+        const uint64_t beg = ptr[row], end = ptr[row + 1];
+        uint64_t base = FILL ? optr[row] : 0, cnt = 0;
+        for (uint64_t i0 = beg; i0 < end; i0 += 64) {
+            const uint64_t i = i0 + lane;
+            const uint64_t e = i < end ? ent[i] : 0;
+            const bool ov = i < end && !ent_regular(e);
+            const unsigned long long m = __ballot(ov);
+            if (FILL && ov) oent[base + __popcll(m & ((1ull << lane) - 1ull))] = e;
+            base += __popcll(m);
+            cnt += __popcll(m);
+        }
+        if (!FILL && lane == 0) optr[row] = cnt;
+    }
+}
+
+// wave per locus column: regular entries -> compact u32 (cell | code<<28) in order; per-code histogram
+template <bool FILL>
+__global__ __launch_bounds__(256) void k_c4_build(uint64_t L, const uint64_t *__restrict__ csc_ptr,
+                                                  const uint64_t *__restrict__ csc_ent, uint64_t *__restrict__ c4_ptr,
+                                                  uint32_t *__restrict__ c4_ent, uint32_t *__restrict__ hist_all)
+{
+    const int lane = threadIdx.x & 63;
+    const uint64_t wave0 = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (uint64_t)gridDim.x * 4;
+    for (uint64_t l = wave0; l < L; l += nwaves) {
+        const uint64_t beg = csc_ptr[l], end = csc_ptr[l + 1];
+        uint64_t base = FILL ? c4_ptr[l] : 0, cnt = 0;
+        uint32_t myhist = 0;
+        for (uint64_t i0 = beg; i0 < end; i0 += 64) {
+            const uint64_t i = i0 + lane;
+            const uint64_t e = i < end ? csc_ent[i] : 0;
+            const bool reg = i < end && ent_regular(e);
+            const uint32_t code = reg ? ent_code(e) : 0xffu;
+            const unsigned long long m = __ballot(reg);
+            if (FILL) {
+                if (reg) c4_ent[base + __popcll(m & ((1ull << lane) - 1ull))] = ENT_IDX(e) | (code << 28);
+            } else {
+#pragma unroll
+                for (int k = 0; k < T_NCODE; k++) {
+                    const unsigned long long mk = __ballot(code == (uint32_t)k);
+                    if (lane == k) myhist += (uint32_t)__popcll(mk);
+                }
+            }
+            base += __popcll(m);
+            cnt += __popcll(m);
+        }
+        if (!FILL) {
+            if (lane == 0) c4_ptr[l] = (cnt + 3) & ~3ull;  // whole 16-byte vectors
+            if (lane < T_NCODE) hist_all[l * T_NCODE + lane] = myhist;
+        } else if ((uint64_t)lane < ((4 - (cnt & 3)) & 3)) {
+            c4_ent[c4_ptr[l] + cnt + lane] = 0xffffffffu;      // padding: code 15 = no entry
+        }
+    }
+}
+
+// ===========================================================================================================
+static inline unsigned gcap(uint64_t n, unsigned per_block, unsigned cap = 1u << 20)
+{
+    uint64_t g = (n + per_block - 1) / per_block;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (unsigned)g;
+}
+
+void tiled_free(cellector_ctx *c)
+{
+    dev_free(c->tile_ptr); dev_free(c->tiles); dev_free(c->ovf_ptr); dev_free(c->ovf_ent);
+    dev_free(c->c4_ptr); dev_free(c->c4_ent); dev_free(c->ovc_ptr); dev_free(c->ovc_ent);
+    dev_free(c->hist_all); dev_free(c->tab); dev_free(c->part); dev_free(c->ab3);
+    dev_free(c->masked_cnt); dev_free(c->flag_bits); dev_free(c->ovf_perm); dev_free(c->ovf_val); dev_free(c->ovf_tab);
+    c->tiled_ready = false;
+    c->ovf_n = 0; c->n_masked_loci = 0;
+}
+
+cellector_status tiled_build(cellector_ctx *c)
+{
+    const uint64_t nloc = c->nloc, L = c->L;
+    if (nloc >= (1ull << 28)) return ctx_fail(c, CELLECTOR_EINVAL, "tiled engine: more than 2^28 cells per shard");
+    c->t_nb = (uint32_t)((nloc + T_BC - 1) / T_BC);
+    c->t_nj = (uint32_t)((L + T_BL - 1) / T_BL);
+    if (c->t_nb == 0) c->t_nb = 1;
+    if (c->t_nj == 0) c->t_nj = 1;
+    c->t_groups = c->t_nj < T_GROUPS ? c->t_nj : T_GROUPS;
+    c->t_cpg = (c->t_nj + c->t_groups - 1) / c->t_groups;
+    c->t_groups = (c->t_nj + c->t_cpg - 1) / c->t_cpg;
+    c->t_npad = (uint64_t)c->t_nb * T_BC;
+    const uint64_t nt = (uint64_t)c->t_nb * c->t_nj;
+
+    // ---- tiles
+    CHK(dev_alloc(c, &c->tile_ptr, nt + 1));
+    HIPCHK(c, hipMemsetAsync(c->tile_ptr + nt, 0, 8, c->stream));
+    const uint64_t maxg = 1ull << 30;
+    for (uint64_t t0 = 0; t0 < nt; t0 += maxg) {
+        const uint64_t g = nt - t0 < maxg ? nt - t0 : maxg;
+        hipLaunchKernelGGL(k_tile_build<false>, dim3((unsigned)g), dim3(T_BC), 0, c->stream, nloc, c->t_nj, t0, c->csr_ptr,
+                           c->csr_ent, c->tile_ptr, (uint16_t *)nullptr);
+    }
+    HIPCHK(c, hipGetLastError());
+    uint64_t elems = 0;
+    CHK(dev_exclusive_scan_u64(c, c->tile_ptr, nt + 1, &elems));
+    CHK(dev_alloc(c, &c->tiles, elems + T_CAP + 8));  // tail pad: the window prefetch may read past the last tile
+    for (uint64_t t0 = 0; t0 < nt; t0 += maxg) {
+        const uint64_t g = nt - t0 < maxg ? nt - t0 : maxg;
+        hipLaunchKernelGGL(k_tile_build<true>, dim3((unsigned)g), dim3(T_BC), 0, c->stream, nloc, c->t_nj, t0, c->csr_ptr,
+                           c->csr_ent, c->tile_ptr, c->tiles);
+    }
+    HIPCHK(c, hipGetLastError());
+
+    // ---- overflow CSR
+    CHK(dev_alloc(c, &c->ovf_ptr, nloc + 1));
+    HIPCHK(c, hipMemsetAsync(c->ovf_ptr + nloc, 0, 8, c->stream));
+    if (nloc)
+        hipLaunchKernelGGL(k_ovf_build<false>, dim3(gcap(nloc, 4)), dim3(256), 0, c->stream, nloc, c->csr_ptr, c->csr_ent,
+                           c->ovf_ptr, (uint64_t *)nullptr);
+    CHK(dev_exclusive_scan_u64(c, c->ovf_ptr, nloc + 1, &c->ovf_n));
+    CHK(dev_alloc(c, &c->ovf_ent, c->ovf_n));
+    if (nloc)
+        hipLaunchKernelGGL(k_ovf_build<true>, dim3(gcap(nloc, 4)), dim3(256), 0, c->stream, nloc, c->csr_ptr, c->csr_ent,
+                           c->ovf_ptr, c->ovf_ent);
+    HIPCHK(c, hipGetLastError());
+
+    // ---- compact CSC + histogram, overflow CSC
+    uint64_t n4 = 0, novc = 0;
+    CHK(dev_alloc(c, &c->c4_ptr, L + 1));
+    CHK(dev_alloc(c, &c->ovc_ptr, L + 1));
+    CHK(dev_alloc(c, &c->hist_all, L * T_NCODE));
+    HIPCHK(c, hipMemsetAsync(c->c4_ptr + L, 0, 8, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->ovc_ptr + L, 0, 8, c->stream));
+    if (L) {
+        hipLaunchKernelGGL(k_c4_build<false>, dim3(gcap(L, 4)), dim3(256), 0, c->stream, L, c->csc_ptr, c->csc_ent,
+                           c->c4_ptr, (uint32_t *)nullptr, c->hist_all);
+        hipLaunchKernelGGL(k_ovf_build<false>, dim3(gcap(L, 4)), dim3(256), 0, c->stream, L, c->csc_ptr, c->csc_ent,
+                           c->ovc_ptr, (uint64_t *)nullptr);
+    }
+    HIPCHK(c, hipGetLastError());
+    CHK(dev_exclusive_scan_u64(c, c->c4_ptr, L + 1, &n4));
+    CHK(dev_exclusive_scan_u64(c, c->ovc_ptr, L + 1, &novc));
+    if (novc != c->ovf_n || n4 < c->nnz - novc)
+        return ctx_fail(c, CELLECTOR_EDEVICE, "internal: tiled build entry counts inconsistent (%llu + %llu vs %llu, ovf %llu)",
+                        (unsigned long long)n4, (unsigned long long)novc, (unsigned long long)c->nnz,
+                        (unsigned long long)c->ovf_n);
+    CHK(dev_alloc(c, &c->c4_ent, n4));
+    CHK(dev_alloc(c, &c->ovc_ent, novc));
+    if (L) {
+        hipLaunchKernelGGL(k_c4_build<true>, dim3(gcap(L, 4)), dim3(256), 0, c->stream, L, c->csc_ptr, c->csc_ent,
+                           c->c4_ptr, c->c4_ent, c->hist_all);
+        hipLaunchKernelGGL(k_ovf_build<true>, dim3(gcap(L, 4)), dim3(256), 0, c->stream, L, c->csc_ptr, c->csc_ent,
+                           c->ovc_ptr, c->ovc_ent);
+    }
+    HIPCHK(c, hipGetLastError());
+
+    // ---- overflow values: by-locus storage + permutation for the by-cell gather
+    if (c->ovf_n >= (1ull << 32)) return ctx_fail(c, CELLECTOR_EINVAL, "tiled engine: more than 2^32 overflow entries per shard");
+    CHK(dev_alloc(c, &c->ovf_perm, c->ovf_n));
+    CHK(dev_alloc(c, &c->ovf_val, 3 * c->ovf_n));
+    CHK(dev_alloc(c, &c->ovf_tab, L * OV_ROW));
+    if (L && c->ovf_n)
+        hipLaunchKernelGGL(k_ovf_perm, dim3(gcap(L, 4)), dim3(256), 0, c->stream, L, c->ovc_ptr, c->ovc_ent, c->ovf_ptr,
+                           c->ovf_ent, c->ovf_perm);
+    HIPCHK(c, hipGetLastError());
+
+    // ---- per-iteration workspaces
+    const uint64_t tab_elems = (uint64_t)c->t_nj * T_W * T_BL;
+    CHK(dev_alloc(c, &c->tab, 3 * tab_elems));
+    CHK(dev_alloc(c, &c->part, 3ull * 2 * c->t_groups * c->t_npad));
+    CHK(dev_alloc(c, &c->ab3, 3 * L));
+    CHK(dev_alloc(c, &c->masked_cnt, nloc));
+    CHK(dev_alloc(c, &c->flag_bits, (nloc + 31) / 32 + 1));
+    HIPCHK(c, hipMemsetAsync(c->masked_cnt, 0, (nloc ? nloc : 1) * 4, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->flag_bits, 0, ((nloc + 31) / 32 + 1) * 4, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->tiled_ready = true;
+    return CELLECTOR_OK;
+}
+
+static cellector_status run_tile_pass(cellector_ctx *c, const double2 *ab, int set, bool expected)
+{
+    const uint64_t tab_elems = (uint64_t)c->t_nj * T_W * T_BL;
+    double *tab = c->tab + (uint64_t)set * tab_elems;
+    double *part_ll = c->part + (uint64_t)set * 2 * c->t_groups * c->t_npad;
+    double *part_ell = part_ll + (uint64_t)c->t_groups * c->t_npad;
+    if (c->ovf_n && c->L) {
+        double2 *val = c->ovf_val + (uint64_t)set * c->ovf_n;
+        hipLaunchKernelGGL(k_ovf_tables, dim3(gcap(c->L, 256)), dim3(256), 0, c->stream, c->L, ab, c->ovf_tab);
+        if (expected)
+            hipLaunchKernelGGL(k_ovf_tables_e, dim3(gcap(c->L * (OV_NE - 3), 256, 0x7fffffffu)), dim3(256), 0, c->stream, c->L,
+                               c->lf, c->ovf_tab);
+        if (expected)
+            hipLaunchKernelGGL(k_ovf_values<true>, dim3(gcap(c->L, 4)), dim3(256), 0, c->stream, c->L, c->ovc_ptr, c->ovc_ent,
+                               ab, c->lf, c->ovf_tab, val);
+        else
+            hipLaunchKernelGGL(k_ovf_values<false>, dim3(gcap(c->L, 4)), dim3(256), 0, c->stream, c->L, c->ovc_ptr, c->ovc_ent,
+                               ab, c->lf, c->ovf_tab, val);
+    }
+    hipLaunchKernelGGL(k_build_tables, dim3(gcap((uint64_t)c->t_nj * T_BL, 256)), dim3(256), 0, c->stream, c->L, c->t_nj,
+                       ab, c->lf, tab, expected ? 1 : 0);
+    const dim3 grid((c->t_nb + T_SB - 1) / T_SB, c->t_groups);
+    timer_begin(c, CELLECTOR_K_TILE_LL);
+    if (expected)
+        hipLaunchKernelGGL(k_tile_ll<true>, grid, dim3(T_THREADS), 0, c->stream, c->t_nb, c->t_nj, c->t_cpg, c->tile_ptr,
+                           c->tiles, tab, c->t_npad, part_ll, part_ell);
+    else
+        hipLaunchKernelGGL(k_tile_ll<false>, grid, dim3(T_THREADS), 0, c->stream, c->t_nb, c->t_nj, c->t_cpg, c->tile_ptr,
+                           c->tiles, tab, c->t_npad, part_ll, part_ell);
+    timer_end(c, CELLECTOR_K_TILE_LL);
+    HIPCHK(c, hipGetLastError());
+    return CELLECTOR_OK;
+}
+
+cellector_status tiled_cell_pass(cellector_ctx *c, const double2 *ab, double *norm_out)
+{
+    if (c->nloc == 0) return CELLECTOR_OK;
+    timer_begin(c, CELLECTOR_K_CELL_LL);
+    CHK(run_tile_pass(c, ab, 0, c->compute_expected));
+    double *part_ll = c->part, *part_ell = c->part + (uint64_t)c->t_groups * c->t_npad;
+    const unsigned grid = gcap(c->nloc, 4);
+    if (c->compute_expected)
+        hipLaunchKernelGGL(k_ovf_finalize<true>, dim3(grid), dim3(256), 0, c->stream, c->nloc, c->ovf_ptr, c->ovf_perm,
+                           c->ovf_val, c->t_groups, c->t_npad, part_ll, part_ell, c->csr_ptr, c->masked_cnt, c->ll, c->ell,
+                           c->nloci, norm_out);
+    else
+        hipLaunchKernelGGL(k_ovf_finalize<false>, dim3(grid), dim3(256), 0, c->stream, c->nloc, c->ovf_ptr, c->ovf_perm,
+                           c->ovf_val, c->t_groups, c->t_npad, part_ll, part_ell, c->csr_ptr, c->masked_cnt, c->ll, c->ell,
+                           c->nloci, norm_out);
+    timer_end(c, CELLECTOR_K_CELL_LL);
+    HIPCHK(c, hipGetLastError());
+    return CELLECTOR_OK;
+}
+
+cellector_status tiled_locus_pass(cellector_ctx *c)
+{
+    if (c->L == 0) return CELLECTOR_OK;
+    timer_begin(c, CELLECTOR_K_LOCUS_STATS);
+    const uint32_t words = (uint32_t)((c->nloc + 31) / 32);
+    if (c->nloc)
+        hipLaunchKernelGGL(k_pack_flag_bits, dim3(gcap(((c->nloc + 63) / 64) * 64, 256)), dim3(256), 0, c->stream, c->nloc,
+                           c->flags_new, c->flag_bits);
+    const size_t lds = (size_t)words * 4;
+    int ncu = 256;
+    (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, c->device);
+    unsigned grid = (unsigned)ncu;
+    const uint64_t need = (c->L + LS_THREADS / 64 - 1) / (LS_THREADS / 64);
+    if (grid > need) grid = (unsigned)(need ? need : 1);
+    if (lds <= 128 * 1024) {
+        HIPCHK(c, hipFuncSetAttribute((const void *)k_locus_stats2<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)(lds ? lds : 4)));
+        hipLaunchKernelGGL(k_locus_stats2<true>, dim3(grid), dim3(LS_THREADS), lds ? lds : 4, c->stream, c->L, words,
+                           c->c4_ptr, c->c4_ent, c->flag_bits, c->hist_all, c->tab, c->mask, c->x_locus);
+    } else {
+        hipLaunchKernelGGL(k_locus_stats2<false>, dim3(grid * 2), dim3(LS_THREADS), 4, c->stream, c->L, words, c->c4_ptr,
+                           c->c4_ent, c->flag_bits, c->hist_all, c->tab, c->mask, c->x_locus);
+    }
+    if (c->ovf_n)
+        hipLaunchKernelGGL(k_locus_ovf, dim3(gcap(c->L, 4)), dim3(256), 0, c->stream, c->L, c->ovc_ptr, c->ovc_ent,
+                           c->ovf_val, c->mask, c->flags_new, c->x_locus);
+    timer_end(c, CELLECTOR_K_LOCUS_STATS);
+    HIPCHK(c, hipGetLastError());
+    return CELLECTOR_OK;
+}
+
+// called after the locus filter with mask = this iteration's mask, mask_next = filtered mask
+cellector_status tiled_masked_update(cellector_ctx *c)
+{
+    if (c->L == 0) return CELLECTOR_OK;
+    hipLaunchKernelGGL(k_masked_update, dim3(gcap(c->L, 4)), dim3(256), 0, c->stream, c->L, c->mask, c->mask_next, c->c4_ptr,
+                       c->c4_ent, c->ovc_ptr, c->ovc_ent, c->masked_cnt);
+    HIPCHK(c, hipGetLastError());
+    return CELLECTOR_OK;
+}
+
+cellector_status tiled_posteriors(cellector_ctx *c, double mf0, double lp_min, double lp_maj, double lp_dbl)
+{
+    const uint64_t L = c->L;
+    if (L)
+        hipLaunchKernelGGL(k_ab_posterior3, dim3(gcap(L, 256)), dim3(256), 0, c->stream, L, c->s_alt, c->s_ref,
+                           c->x_locus + LB_ALT_MIN * L, c->x_locus + LB_REF_MIN * L, mf0, c->ab3, c->ab6);
+    HIPCHK(c, hipGetLastError());
+    if (c->nloc == 0) return CELLECTOR_OK;
+    timer_begin(c, CELLECTOR_K_POSTERIOR);
+    for (int set = 0; set < 3; set++) CHK(run_tile_pass(c, c->ab3 + (uint64_t)set * L, set, false));
+    hipLaunchKernelGGL(k_posterior_finalize, dim3(gcap(c->nloc, 4)), dim3(256), 0, c->stream, c->nloc, c->ovf_ptr,
+                       c->ovf_perm, c->ovf_val, c->ovf_n, c->t_groups, c->t_npad, c->part, lp_min, lp_maj, lp_dbl, c->post);
+    timer_end(c, CELLECTOR_K_POSTERIOR);
+    HIPCHK(c, hipGetLastError());
+    return CELLECTOR_OK;
+}

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcellector_hip.so")
 
 XCHG_PASS1, XCHG_NORM, XCHG_LOCUS = 0, 1, 2
-K_CELL_LL, K_LOCUS_STATS, K_SELECT, K_POSTERIOR = 0, 1, 2, 3
+K_CELL_LL, K_LOCUS_STATS, K_SELECT, K_POSTERIOR, K_TILE_LL = 0, 1, 2, 3, 4
 STATUS_NAMES = {0: "OK", 1: "EINVAL", 2: "EIO", 3: "EPARSE", 4: "ENOMEM", 5: "EDEVICE", 6: "ECOMM"}
 
 # every entry point include/cellector_ffi.h declares: name -> (restype, argtypes)
@@ -50,6 +50,7 @@ SIGNATURES = {
     "cellector_cell_log_likelihoods": (_i, [_vp] + [_vp] * 6),
     "cellector_posteriors": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "cellector_final_allele_tallies": (_i, [_vp, _vp, _vp, _vp, _vp]),
+    "cellector_engine_info": (_i, [_vp, _vp]),
     "cellector_kernel_time": (_i, [_vp, _i, C.POINTER(_d), C.POINTER(_u64)]),
     "cellector_reset_timing": (_i, [_vp]),
 }
@@ -58,6 +59,11 @@ SIGNATURES = {
 class Dims(C.Structure):
     _fields_ = [("total_cells", _u64), ("total_loci", _u64), ("loci_used", _u64), ("cell_begin", _u64),
                 ("cell_end", _u64), ("nnz_used", _u64)]
+
+
+class EngineInfo(C.Structure):
+    _fields_ = [("engine", _u64), ("nnz_regular", _u64), ("nnz_overflow", _u64), ("tile_bytes", _u64),
+                ("cell_blocks", _u64), ("locus_chunks", _u64), ("chunk_groups", _u64), ("reserved", _u64)]
 
 
 class IterSummary(C.Structure):
@@ -281,6 +287,11 @@ class Cellector:
         outs = [np.empty(tl, np.uint64) for _ in range(4)]
         self._ck(self._lib.cellector_final_allele_tallies(self.h, *[_p(o) for o in outs]))
         return dict(zip(["alt_min", "ref_min", "alt_maj", "ref_maj"], outs))
+
+    def engine_info(self):
+        e = EngineInfo()
+        self._ck(self._lib.cellector_engine_info(self.h, C.byref(e)))
+        return e
 
     # ---- timing
     def kernel_time(self, which):

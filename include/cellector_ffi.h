@@ -50,7 +50,10 @@ const char *cellector_version(void);
 cellector_status cellector_set_stream(cellector_ctx *ctx, void *hip_stream);
 /* Options: "compute_expected" (default 1: also accumulate expected_log_beta_binomial_pmf,
  * stats.rs:8-33, into expected_ll like the reference; 0 = skip that diagnostic column),
- * "timing" (default 0: record HIP events around the dominant kernels). */
+ * "timing" (default 0: record HIP events around the dominant kernels),
+ * "keep_coo" (default 1: keep the staged all-loci COO for cellector_final_allele_tallies),
+ * "engine" (default 2: table-driven passes over the tiled 16-bit layout; 1: CSR/CSC kernels that
+ * evaluate every entry's log-pmf — same results within rounding, kept for A/B checks). */
 cellector_status cellector_set_option(cellector_ctx *ctx, const char *key, int64_t value);
 
 /* ---- sharding (before ingest) --------------------------------------------------------------- */
@@ -170,13 +173,25 @@ cellector_status cellector_posteriors(cellector_ctx *ctx, double *posterior, dou
 cellector_status cellector_final_allele_tallies(cellector_ctx *ctx, uint64_t *alt_min, uint64_t *ref_min,
                                                 uint64_t *alt_maj, uint64_t *ref_maj /*[total_loci]*/);
 
+/* layout facts of the loaded shard (benchmark accounting) */
+typedef struct {
+    uint64_t engine;
+    uint64_t nnz_regular;   /* entries with 1 <= alt+ref <= 3: handled by table lookup in the tiled passes */
+    uint64_t nnz_overflow;  /* the rest: evaluated individually                                           */
+    uint64_t tile_bytes;    /* bytes of the tiled cell-pass layout                                        */
+    uint64_t cell_blocks, locus_chunks, chunk_groups;
+    uint64_t reserved;
+} cellector_engine_info_t;
+cellector_status cellector_engine_info(const cellector_ctx *ctx, cellector_engine_info_t *out);
+
 /* ---- timing of the dominant kernels (HIP events on the ctx stream; option "timing") ---------- */
 typedef enum {
     CELLECTOR_K_CELL_LL = 0,     /* per-cell log-likelihood pass over the CSR  */
     CELLECTOR_K_LOCUS_STATS = 1, /* per-locus pass over the CSC                */
     CELLECTOR_K_SELECT = 2,      /* order statistics                           */
     CELLECTOR_K_POSTERIOR = 3,   /* fused 3-distribution pass + posteriors     */
-    CELLECTOR_K_COUNT = 4
+    CELLECTOR_K_TILE_LL = 4,     /* engine 2: the tiled table-lookup kernel alone (inside K_CELL_LL) */
+    CELLECTOR_K_COUNT = 5
 } cellector_kernel_id;
 cellector_status cellector_kernel_time(cellector_ctx *ctx, cellector_kernel_id which,
                                        double *total_ms, uint64_t *launches);

@@ -20,10 +20,18 @@ LL_ATOL = 1e-7
 POST_ATOL = 1e-6
 
 
-@pytest.fixture(scope="module")
-def mods(oracle_lib, hip_lib_path):
+@pytest.fixture(scope="module", params=[2, 1], ids=["tiled", "csr"])
+def mods(request, oracle_lib, hip_lib_path):
+    """Every parity test runs against both engines: 2 = table-driven tiled passes (default), 1 = CSR/CSC kernels."""
     from cellector_amd import Cellector, ffi, synth
-    return dict(Cellector=Cellector, ffi=ffi, synth=synth, ob=oracle_lib)
+    engine = request.param
+
+    def make(device=0):
+        g = Cellector(device)
+        g.set_option("engine", engine)
+        return g
+
+    return dict(Cellector=make, ffi=ffi, synth=synth, ob=oracle_lib, engine=engine)
 
 
 def _case(mods, L, N, d, seed=4, minority=0.05, doublet=0.0, min_alt=4, min_ref=4):
@@ -104,6 +112,11 @@ def test_synthetic_generator_matches_host_twin(mods):
         g.load_synthetic(L, N, d, seed=11, minority_fraction=0.07, doublet_fraction=0.02, min_alt=0, min_ref=0)
         o = mods["ob"].Oracle.from_coo(L, N, lo, ce, al, re, 0, 0)
         _check_matrix(g, o)
+        info = g.engine_info()
+        assert info.engine == mods["engine"]
+        if mods["engine"] == 2:
+            assert info.nnz_regular + info.nnz_overflow == o.nnz and 0 < info.nnz_overflow < 0.06 * o.nnz
+            assert info.cell_blocks == 40 and info.locus_chunks == 1
 
 
 def test_cfg1_full_loop_and_posteriors(mods):
