@@ -77,38 +77,61 @@ __global__ __launch_bounds__(SEL_BLOCK) void k_sel_hist(const double *__restrict
     }
 }
 
-// one wave: for each target walk its (leader's) histogram to the bin containing the remaining rank
+// one wave: for each target find the bin of its (leader's) histogram that holds the remaining rank.
+// Lane i owns bins 4i..4i+3; a shuffle scan over the lane sums locates the lane, then the bin inside it.
 __global__ void k_sel_step(int pass, uint64_t *__restrict__ state, uint32_t *__restrict__ hist)
 {
-    __shared__ uint64_t prefix[SEL_T];
-    __shared__ uint64_t newst[SEL_T][2];
-    const int t = threadIdx.x;
-    if (t < SEL_T) prefix[t] = state[2 * t];
-    __syncthreads();
-    if (t < SEL_T) {
+    const int lane = threadIdx.x;
+    uint64_t prefix[SEL_T], rank[SEL_T], newp[SEL_T], newr[SEL_T];
+#pragma unroll
+    for (int t = 0; t < SEL_T; t++) {
+        prefix[t] = state[2 * t];
+        rank[t] = state[2 * t + 1];
+    }
+    const int shift = 56 - 8 * pass;
+#pragma unroll
+    for (int t = 0; t < SEL_T; t++) {
         int ld = t;
-        for (int u = 0; u < t; u++)
-            if (prefix[u] == prefix[t]) { ld = u; break; }
-        uint64_t rank = state[2 * t + 1];
-        const uint32_t *h = hist + ld * 256;
-        uint64_t cum = 0;
-        int d = 0;
-        for (; d < 255; d++) {
-            const uint64_t c = h[d];
-            if (cum + c > rank) break;
-            cum += c;
+#pragma unroll
+        for (int u = SEL_T - 1; u >= 0; u--)
+            if (u < t && prefix[u] == prefix[t]) ld = u;
+        const uint4 h = reinterpret_cast<const uint4 *>(hist + ld * 256)[lane];
+        const uint32_t lsum = h.x + h.y + h.z + h.w;
+        uint32_t inc = lsum;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t o = __shfl_up(inc, off, 64);
+            if (lane >= off) inc += o;
         }
-        const int shift = 56 - 8 * pass;
-        newst[t][0] = prefix[t] | ((uint64_t)d << shift);
-        newst[t][1] = rank - cum;
+        const uint64_t exc = inc - lsum;
+        // the lane whose bins contain the rank (the last lane if counts are short: defensive, cannot happen)
+        const bool mine = (exc <= rank[t] && rank[t] < (uint64_t)inc) || (lane == 63 && rank[t] >= (uint64_t)inc);
+        uint32_t d = 0;
+        uint64_t cum = exc;
+        if (mine) {
+            const uint32_t hs[4] = {h.x, h.y, h.z, h.w};
+            d = 4 * lane;
+#pragma unroll
+            for (int q = 0; q < 3; q++) {
+                if (cum + hs[q] <= rank[t] && d == (uint32_t)(4 * lane + q)) { cum += hs[q]; d++; }
+            }
+        }
+        const unsigned long long who = __ballot(mine);
+        const int src = __ffsll((long long)who) - 1;
+        const uint32_t dsel = (uint32_t)__shfl((int)d, src, 64);
+        const uint64_t cumsel = (uint64_t)__shfl((long long)cum, src, 64);
+        newp[t] = prefix[t] | ((uint64_t)dsel << shift);
+        newr[t] = rank[t] - cumsel;
     }
     __syncthreads();
-    if (t < SEL_T) {
-        state[2 * t] = newst[t][0];
-        state[2 * t + 1] = newst[t][1];
+    if (lane == 0) {
+#pragma unroll
+        for (int t = 0; t < SEL_T; t++) {
+            state[2 * t] = newp[t];
+            state[2 * t + 1] = newr[t];
+        }
     }
-    __syncthreads();
-    for (int i = threadIdx.x; i < SEL_T * 256; i += blockDim.x) hist[i] = 0;  // ready for the next pass
+    for (int i = lane; i < SEL_T * 256; i += 64) hist[i] = 0;  // ready for the next pass
 }
 
 __global__ void k_sel_finish(const uint64_t *__restrict__ state, double *__restrict__ out)

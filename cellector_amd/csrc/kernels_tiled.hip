@@ -18,11 +18,10 @@
 #include "ctx.h"
 #include "device_math.h"
 
-#define T_K 3
-#define T_NCODE 9
-#define T_W 12
-#define T_BL 512
-#define T_BLOG 9
+#define T_K 4           // entries with 1 <= alt+ref <= T_K are "regular": log-pmf and expected term come from tables
+#define T_NCODE 14      // (alt, ref) combinations with 1 <= n <= T_K: K(K+3)/2
+#define T_W 18          // table doubles per locus: T_NCODE log-pmfs + T_K expected terms
+#define T_BL 384        // loci per chunk: T_W * T_BL * 8 = 54 KB of LDS
 #define T_BC 1024       // cells per block == threads per workgroup: one lane per cell
 #define T_THREADS 1024
 #ifndef T_SB
@@ -31,10 +30,15 @@
 #define T_CAP 6144      // entries of one tile staged per window (12 KB)
 #define T_GROUPS 8
 #define T_HDR 2056      // tile header in u16 units: (T_BC + 1) u32 exclusive offsets, padded to 16 bytes
-#define T_IDX_MASK 0x1fffu  // entry bits 0..12 = code*512 + locus_in_chunk (the table index); bits 13..14 = n-1
+#define T_NP ((T_W * T_BL / 2 + T_THREADS - 1) / T_THREADS)  // double2 table prefetch registers per lane
+// tile entry (u16): bits 0..3 code, 4..12 locus_in_chunk, 13..14 n-1
+#define TE_CODE(e) ((e) & 15u)
+#define TE_LOC(e) (((e) >> 4) & 511u)
+#define TE_NM1(e) ((e) >> 13)
 
-__device__ __constant__ uint8_t T_A_OF[T_NCODE] = {1, 0, 2, 1, 0, 3, 2, 1, 0};
-__device__ __constant__ uint8_t T_R_OF[T_NCODE] = {0, 1, 0, 1, 2, 0, 1, 2, 3};
+// code = n(n+1)/2 - 1 + ref:  n=1: (1,0)(0,1)  n=2: (2,0)(1,1)(0,2)  n=3: (3,0)..(0,3)  n=4: (4,0)..(0,4)
+__device__ __constant__ uint8_t T_A_OF[T_NCODE] = {1, 0, 2, 1, 0, 3, 2, 1, 0, 4, 3, 2, 1, 0};
+__device__ __constant__ uint8_t T_R_OF[T_NCODE] = {0, 1, 0, 1, 2, 0, 1, 2, 3, 0, 1, 2, 3, 4};
 
 __device__ __forceinline__ bool ent_regular(uint64_t e)
 {
@@ -56,7 +60,7 @@ __global__ void k_build_tables(uint64_t L, uint32_t nj, const double2 *__restric
 {
     const uint64_t l = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (l >= (uint64_t)nj * T_BL) return;
-    double *row = tab + (l >> T_BLOG) * (uint64_t)(T_W * T_BL) + (l & (T_BL - 1));
+    double *row = tab + (l / T_BL) * (uint64_t)(T_W * T_BL) + (l % T_BL);
     double2 p = make_double2(-1.0, -1.0);
     if (l < L) p = ab[l];
     const bool live = p.x >= 0.0;
@@ -78,7 +82,7 @@ __global__ __launch_bounds__(T_THREADS, 8) void k_tile_ll(uint32_t nb, uint32_t 
                                                           const double *__restrict__ tab, uint64_t npad,
                                                           double *__restrict__ part_ll, double *__restrict__ part_ell)
 {
-    __shared__ double s_tab[T_W * T_BL];      // 48 KB: this chunk's table, [w][locus]
+    __shared__ double s_tab[T_W * T_BL];      // 54 KB: this chunk's table, [w][locus]
     __shared__ uint4 s_ent[T_SB][T_CAP / 8];  // staged tile entries (first window of each cell block)
     const uint32_t tid = threadIdx.x;
     const uint32_t b0 = blockIdx.x * T_SB, g = blockIdx.y;
@@ -88,8 +92,8 @@ __global__ __launch_bounds__(T_THREADS, 8) void k_tile_ll(uint32_t nb, uint32_t 
     for (int s = 0; s < T_SB; s++) ll[s] = el[s] = 0.0;
 
     // registers that carry the NEXT chunk's data while the current one is being consumed
-    static_assert(T_W * T_BL / 2 / T_THREADS == 3, "table prefetch registers are written out by hand");
-    double2 p_tab0, p_tab1, p_tab2;
+    static_assert(T_NP == 4, "table prefetch registers are written out by hand");
+    double2 p_tab0, p_tab1, p_tab2, p_tab3 = make_double2(0.0, 0.0);
     uint32_t p_beg[T_SB], p_end[T_SB], p_tot[T_SB];
     uint4 p_ent[T_SB];
 #define TILE_PREFETCH(J)                                                                                        \
@@ -98,6 +102,7 @@ __global__ __launch_bounds__(T_THREADS, 8) void k_tile_ll(uint32_t nb, uint32_t 
         p_tab0 = src__[tid];                                                                                    \
         p_tab1 = src__[tid + T_THREADS];                                                                        \
         p_tab2 = src__[tid + 2 * T_THREADS];                                                                    \
+        if (tid + 3 * T_THREADS < T_W * T_BL / 2) p_tab3 = src__[tid + 3 * T_THREADS];                          \
         _Pragma("unroll") for (int s = 0; s < T_SB; s++) {                                                     \
             p_beg[s] = p_end[s] = p_tot[s] = 0;                                                                 \
             p_ent[s] = make_uint4(0, 0, 0, 0);                                                                  \
@@ -121,6 +126,7 @@ __global__ __launch_bounds__(T_THREADS, 8) void k_tile_ll(uint32_t nb, uint32_t 
             dst[tid] = p_tab0;
             dst[tid + T_THREADS] = p_tab1;
             dst[tid + 2 * T_THREADS] = p_tab2;
+            if (tid + 3 * T_THREADS < T_W * T_BL / 2) dst[tid + 3 * T_THREADS] = p_tab3;
 #pragma unroll
             for (int s = 0; s < T_SB; s++)
                 if (tid < T_CAP / 8) s_ent[s][tid] = p_ent[s];
@@ -145,9 +151,9 @@ __global__ __launch_bounds__(T_THREADS, 8) void k_tile_ll(uint32_t nb, uint32_t 
                 }
                 const uint32_t klo = max(my_s[s], w0), khi = min(my_e[s], w0 + n_in);
                 for (uint32_t k = klo; k < khi; ++k) {
-                    const uint32_t e = se[k - w0];
-                    a_ll += s_tab[e & T_IDX_MASK];
-                    if (EXPECTED) a_el += s_tab[((e >> 13) + T_NCODE) * T_BL + (e & (T_BL - 1))];
+                    const uint32_t e = se[k - w0], loc = TE_LOC(e);
+                    a_ll += s_tab[TE_CODE(e) * T_BL + loc];
+                    if (EXPECTED) a_el += s_tab[(TE_NM1(e) + T_NCODE) * T_BL + loc];
                 }
             }
             ll[s] = a_ll;
@@ -292,7 +298,8 @@ __global__ __launch_bounds__(256) void k_ovf_perm(uint64_t L, const uint64_t *__
     }
 }
 
-// cell side: gather the overflow values, join the chunk-group partials in one fixed-shape shuffle tree, normalise
+// cell side: one THREAD per cell row: chunk-group partials in group order, then the row's overflow values in
+// ascending-locus order through the permutation (sequential sums: deterministic), then the normalisation.
 template <bool EXPECTED>
 __global__ __launch_bounds__(256) void k_ovf_finalize(uint64_t n_rows, const uint64_t *__restrict__ ovf_ptr,
                                                       const uint32_t *__restrict__ perm,
@@ -304,30 +311,30 @@ __global__ __launch_bounds__(256) void k_ovf_finalize(uint64_t n_rows, const uin
                                                       double *__restrict__ ell, double *__restrict__ nloci,
                                                       double *__restrict__ norm_out)
 {
-    const int lane = threadIdx.x & 63;
-    const uint64_t wave0 = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (uint64_t)gridDim.x * 4;
-    for (uint64_t row = wave0; row < n_rows; row += nwaves) {
-        const uint64_t beg = ovf_ptr[row], end = ovf_ptr[row + 1];
-        double s = 0.0, e = 0.0;
-        for (uint64_t i = beg + lane; i < end; i += 64) {
-            const double2 v = val[perm[i]];
-            s += v.x;
-            if (EXPECTED) e += v.y;
-        }
-        if ((uint32_t)lane < groups) {
-            s += part_ll[(uint64_t)lane * npad + row];
-            if (EXPECTED) e += part_ell[(uint64_t)lane * npad + row];
-        }
-        s = wave_sum(s);
-        if (EXPECTED) e = wave_sum(e);
-        if (lane == 0) {
-            const double cnt = (double)((csr_ptr[row + 1] - csr_ptr[row]) - (uint64_t)masked_cnt[row]);
-            ll[row] = s;
-            if (EXPECTED) ell[row] = e;
-            nloci[row] = cnt;
-            if (norm_out) norm_out[row] = cnt > 0.0 ? s / cnt : 0.0;  // main.rs:315-322
-        }
+    const uint64_t row = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= n_rows) return;
+    double s = 0.0, e = 0.0;
+    for (uint32_t g = 0; g < groups; g++) {
+        s += part_ll[(uint64_t)g * npad + row];
+        if (EXPECTED) e += part_ell[(uint64_t)g * npad + row];
     }
+    const uint64_t beg = ovf_ptr[row], end = ovf_ptr[row + 1];
+    uint64_t i = beg;
+    for (; i + 4 <= end; i += 4) {  // four independent gathers in flight
+        const double2 v0 = val[perm[i]], v1 = val[perm[i + 1]], v2 = val[perm[i + 2]], v3 = val[perm[i + 3]];
+        s += v0.x; s += v1.x; s += v2.x; s += v3.x;
+        if (EXPECTED) { e += v0.y; e += v1.y; e += v2.y; e += v3.y; }
+    }
+    for (; i < end; i++) {
+        const double2 v = val[perm[i]];
+        s += v.x;
+        if (EXPECTED) e += v.y;
+    }
+    const double cnt = (double)((csr_ptr[row + 1] - csr_ptr[row]) - (uint64_t)masked_cnt[row]);
+    ll[row] = s;
+    if (EXPECTED) ell[row] = e;
+    nloci[row] = cnt;
+    if (norm_out) norm_out[row] = cnt > 0.0 ? s / cnt : 0.0;  // main.rs:315-322
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -342,6 +349,7 @@ __global__ void k_pack_flag_bits(uint64_t n, const uint8_t *__restrict__ flags, 
 }
 
 #define LS_THREADS 1024
+#define LS_NPK ((T_NCODE + 4) / 5)
 #define LS_FLUSH 15  // vector iterations between wave reductions: 15*4 = 60 per lane and field, 64*60 < 4096 (12-bit fields)
 template <bool BITS_IN_LDS>
 __global__ __launch_bounds__(LS_THREADS) void k_locus_stats2(uint64_t L, uint32_t nbits_words,
@@ -353,10 +361,12 @@ __global__ __launch_bounds__(LS_THREADS) void k_locus_stats2(uint64_t L, uint32_
                                                              const uint8_t *__restrict__ mask, double *__restrict__ out)
 {
     extern __shared__ uint32_t s_bits[];
-    if (BITS_IN_LDS) {
+    __shared__ uint32_t s_whist[LS_THREADS / 64][16];
+    if (threadIdx.x < (LS_THREADS / 64) * 16) (&s_whist[0][0])[threadIdx.x] = 0;
+    if (BITS_IN_LDS)
         for (uint32_t i = threadIdx.x; i < nbits_words; i += LS_THREADS) s_bits[i] = flag_bits[i];
-        __syncthreads();
-    }
+    __syncthreads();
+    uint32_t *whist = s_whist[threadIdx.x >> 6];
     const uint32_t *bits = BITS_IN_LDS ? s_bits : flag_bits;
     const int lane = threadIdx.x & 63;
     const uint64_t wave0 = (uint64_t)blockIdx.x * (LS_THREADS / 64) + (threadIdx.x >> 6);
@@ -365,41 +375,32 @@ __global__ __launch_bounds__(LS_THREADS) void k_locus_stats2(uint64_t L, uint32_
         // columns are padded to whole 16-byte vectors with 0xFFFFFFFF (code 15 = no entry)
         const uint64_t vbeg = c4_ptr[l] >> 2, nvec = (c4_ptr[l + 1] >> 2) - vbeg;
         const uint4 *vp = reinterpret_cast<const uint4 *>(c4_ent) + vbeg;
-        uint32_t tot[T_NCODE];  // lane 0: minority entries per code
+        // minority entries are few: they vote into this wave's 16-bin LDS histogram (integer atomics: exact)
+        for (uint64_t i0 = 0; i0 < nvec; i0 += 4 * 64) {
+            // four independent 16-byte loads per lane in flight (4 KB per wave): the pass is a pure stream
+            uint4 v[4];
 #pragma unroll
-        for (int k = 0; k < T_NCODE; k++) tot[k] = 0;
-        uint64_t pa = 0, pb = 0;  // packed 12-bit counters: codes 0..4 in pa, 5..8 in pb
-        uint32_t since = 0;
-        for (uint64_t i0 = 0; i0 < nvec; i0 += 64) {
-            const uint64_t i = i0 + lane;
-            uint4 v = make_uint4(~0u, ~0u, ~0u, ~0u);
-            if (i < nvec) v = vp[i];
-            const uint32_t xs[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const uint32_t x = xs[q], code = x >> 28;
-                const bool valid = code < (uint32_t)T_NCODE;
-                const uint32_t cell = valid ? (x & 0x0fffffffu) : 0u;
-                const uint64_t inc = valid ? (uint64_t)((bits[cell >> 5] >> (cell & 31)) & 1u) : 0ull;
-                if (code < 5u) pa += inc << (12u * code);
-                else pb += inc << (12u * ((code - 5u) & 3u));
+            for (int u = 0; u < 4; u++) {
+                const uint64_t i = i0 + (uint64_t)u * 64 + lane;
+                v[u] = make_uint4(~0u, ~0u, ~0u, ~0u);
+                if (i < nvec) v[u] = vp[i];
             }
-            if (++since == LS_FLUSH || i0 + 64 >= nvec) {  // wave-uniform
-                const uint64_t sa = wave_sum_u64(pa), sb = wave_sum_u64(pb);
 #pragma unroll
-                for (int k = 0; k < 5; k++) tot[k] += (uint32_t)(sa >> (12 * k)) & 0xfffu;
+            for (int u = 0; u < 4; u++) {
+                const uint32_t xs[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
 #pragma unroll
-                for (int k = 5; k < T_NCODE; k++) tot[k] += (uint32_t)(sb >> (12 * (k - 5))) & 0xfffu;
-                pa = pb = 0;
-                since = 0;
+                for (int q = 0; q < 4; q++) {
+                    const uint32_t x = xs[q], code = x >> 28;
+                    const uint32_t cell = code < (uint32_t)T_NCODE ? (x & 0x0fffffffu) : 0u;
+                    if (code < (uint32_t)T_NCODE && ((bits[cell >> 5] >> (cell & 31)) & 1u)) atomicAdd(&whist[code], 1u);
+                }
             }
         }
-        // lane k < 9 takes code k: minority count (from lane 0), static histogram, table value
+        // lane k < T_NCODE takes code k (same wave wrote the bins: LDS operations of one wave complete in order)
         uint32_t mycnt = 0;
-#pragma unroll
-        for (int k = 0; k < T_NCODE; k++) {
-            const uint32_t t0 = (uint32_t)__shfl((int)tot[k], 0, 64);
-            if (lane == k) mycnt = t0;
+        if (lane < 16) {
+            mycnt = whist[lane];
+            whist[lane] = 0;
         }
         const bool live = mask[l] != 0;
         double cmin = 0.0, cmaj = 0.0;
@@ -410,7 +411,7 @@ __global__ __launch_bounds__(LS_THREADS) void k_locus_stats2(uint64_t L, uint32_
             amin = mycnt * T_A_OF[lane];
             rmin = mycnt * T_R_OF[lane];
             if (live) {
-                const double t = tab[(l >> T_BLOG) * (uint64_t)(T_W * T_BL) + (uint64_t)lane * T_BL + (l & (T_BL - 1))];
+                const double t = tab[(l / T_BL) * (uint64_t)(T_W * T_BL) + (uint64_t)lane * T_BL + (l % T_BL)];
                 cmin = (double)mycnt * t;
                 cmaj = (double)(all - mycnt) * t;
             }
@@ -520,36 +521,31 @@ __global__ __launch_bounds__(256) void k_posterior_finalize(uint64_t n_rows, con
                                                             double lp_min, double lp_maj, double lp_dbl,
                                                             double *__restrict__ post)
 {
-    const int lane = threadIdx.x & 63;
-    const uint64_t wave0 = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (uint64_t)gridDim.x * 4;
+    const uint64_t row = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= n_rows) return;
     const uint64_t set_stride = 2ull * groups * npad;
-    for (uint64_t row = wave0; row < n_rows; row += nwaves) {
-        const uint64_t beg = ovf_ptr[row], end = ovf_ptr[row + 1];
-        double s0 = 0.0, s1 = 0.0, s2 = 0.0;
-        for (uint64_t i = beg + lane; i < end; i += 64) {
-            const uint64_t p = perm[i];
-            s0 += val[p].x;
-            s1 += val[ovf_n + p].x;
-            s2 += val[2 * ovf_n + p].x;
-        }
-        if ((uint32_t)lane < groups) {
-            s0 += part[(uint64_t)lane * npad + row];
-            s1 += part[set_stride + (uint64_t)lane * npad + row];
-            s2 += part[2 * set_stride + (uint64_t)lane * npad + row];
-        }
-        s0 = wave_sum(s0); s1 = wave_sum(s1); s2 = wave_sum(s2);
-        if (lane == 0) {
-            const double s_min = s0, s_maj = s1, s_dbl = s2;
-            const double log_num = lp_min + s_min;                       // main.rs:267
-            double log_den = dm_logsumexp(log_num, lp_maj + s_maj);      // main.rs:268
-            const double log_dbl = lp_dbl + s_dbl;                       // main.rs:270
-            log_den = dm_logsumexp(log_den, log_dbl);                    // main.rs:271
-            post[row] = exp(log_num - log_den);
-            post[n_rows + row] = exp(log_dbl - log_den);
-            post[2 * n_rows + row] = s_maj;
-            post[3 * n_rows + row] = s_min;
-        }
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+    for (uint32_t g = 0; g < groups; g++) {
+        s0 += part[(uint64_t)g * npad + row];
+        s1 += part[set_stride + (uint64_t)g * npad + row];
+        s2 += part[2 * set_stride + (uint64_t)g * npad + row];
     }
+    const uint64_t beg = ovf_ptr[row], end = ovf_ptr[row + 1];
+    for (uint64_t i = beg; i < end; i++) {
+        const uint64_t p = perm[i];
+        s0 += val[p].x;
+        s1 += val[ovf_n + p].x;
+        s2 += val[2 * ovf_n + p].x;
+    }
+    const double s_min = s0, s_maj = s1, s_dbl = s2;
+    const double log_num = lp_min + s_min;                       // main.rs:267
+    double log_den = dm_logsumexp(log_num, lp_maj + s_maj);      // main.rs:268
+    const double log_dbl = lp_dbl + s_dbl;                       // main.rs:270
+    log_den = dm_logsumexp(log_den, log_dbl);                    // main.rs:271
+    post[row] = exp(log_num - log_den);
+    post[n_rows + row] = exp(log_dbl - log_den);
+    post[2 * n_rows + row] = s_maj;
+    post[3 * n_rows + row] = s_min;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -611,7 +607,7 @@ __global__ __launch_bounds__(T_BC) void k_tile_build(uint64_t nloc, uint32_t nj,
     for (uint64_t i = lo; i < hi; i++) {
         const uint64_t e = csr_ent[i];
         if (ent_regular(e))
-            *dst++ = (uint16_t)(((ENT_ALT(e) + ENT_REF(e) - 1u) << 13) | (ent_code(e) << T_BLOG) | (ENT_IDX(e) - j * T_BL));
+            *dst++ = (uint16_t)(((ENT_ALT(e) + ENT_REF(e) - 1u) << 13) | ((ENT_IDX(e) - j * T_BL) << 4) | ent_code(e));
     }
     // zero the padding so that staged vectors never carry garbage
     if (cl == 0) {
@@ -843,7 +839,7 @@ cellector_status tiled_cell_pass(cellector_ctx *c, const double2 *ab, double *no
     timer_begin(c, CELLECTOR_K_CELL_LL);
     CHK(run_tile_pass(c, ab, 0, c->compute_expected));
     double *part_ll = c->part, *part_ell = c->part + (uint64_t)c->t_groups * c->t_npad;
-    const unsigned grid = gcap(c->nloc, 4);
+    const unsigned grid = gcap(c->nloc, 256, 0x7fffffffu);
     if (c->compute_expected)
         hipLaunchKernelGGL(k_ovf_finalize<true>, dim3(grid), dim3(256), 0, c->stream, c->nloc, c->ovf_ptr, c->ovf_perm,
                            c->ovf_val, c->t_groups, c->t_npad, part_ll, part_ell, c->csr_ptr, c->masked_cnt, c->ll, c->ell,
@@ -908,7 +904,7 @@ cellector_status tiled_posteriors(cellector_ctx *c, double mf0, double lp_min, d
     if (c->nloc == 0) return CELLECTOR_OK;
     timer_begin(c, CELLECTOR_K_POSTERIOR);
     for (int set = 0; set < 3; set++) CHK(run_tile_pass(c, c->ab3 + (uint64_t)set * L, set, false));
-    hipLaunchKernelGGL(k_posterior_finalize, dim3(gcap(c->nloc, 4)), dim3(256), 0, c->stream, c->nloc, c->ovf_ptr,
+    hipLaunchKernelGGL(k_posterior_finalize, dim3(gcap(c->nloc, 256, 0x7fffffffu)), dim3(256), 0, c->stream, c->nloc, c->ovf_ptr,
                        c->ovf_perm, c->ovf_val, c->ovf_n, c->t_groups, c->t_npad, c->part, lp_min, lp_maj, lp_dbl, c->post);
     timer_end(c, CELLECTOR_K_POSTERIOR);
     HIPCHK(c, hipGetLastError());
