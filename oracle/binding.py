@@ -59,6 +59,7 @@ def lib():
         "orc_set_excluded": (None, [vp, vp]), "orc_alpha_betas": (None, [vp, vp, vp]),
         "orc_cell_log_likelihoods": (None, [vp] + [vp] * 6),
         "orc_posteriors": (None, [vp, vp, vp, vp, vp]),
+        "orc_locus_stats": (None, [vp] + [vp] * 12),
         "orc_assignments": (None, [vp, vp, vp, d, u64, vp, vp, vp]),
         "orc_final_tallies_coo": (None, [u64, u64] + [vp] * 9),
         "orc_vcf_genotype": (None, [u64, u64, u64, u64, vp, vp, vp, vp]),
@@ -185,6 +186,17 @@ class Oracle:
         ll, ell, nl = (np.empty(n, np.float64) for _ in range(3))
         lib().orc_cell_log_likelihoods(self.h, _p(alpha), _p(beta), _p(mask), _p(ll), _p(ell), _p(nl))
         return ll, ell, nl
+
+    def locus_stats(self, alpha, beta, mask, new_excluded):
+        L = self.loci_used
+        alpha = np.ascontiguousarray(alpha, np.float64); beta = np.ascontiguousarray(beta, np.float64)
+        mask = np.ascontiguousarray(mask, np.uint8); new_excluded = np.ascontiguousarray(new_excluded, np.uint8)
+        cm, cj = np.empty(L, np.float64), np.empty(L, np.float64)
+        ints = [np.empty(L, np.uint64) for _ in range(6)]
+        lib().orc_locus_stats(self.h, _p(alpha), _p(beta), _p(mask), _p(new_excluded), _p(cm), _p(cj),
+                              *[_p(a) for a in ints])
+        keys = ["cells_min", "cells_maj", "alt_min", "ref_min", "alt_maj", "ref_maj"]
+        return dict(contrib_min=cm, contrib_maj=cj, **dict(zip(keys, ints)))
 
     def posteriors(self):
         n = self.total_cells

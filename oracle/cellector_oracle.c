@@ -643,6 +643,20 @@ void orc_loci_mask(const orc_ctx *c, uint8_t *out) { memcpy(out, c->loci_used, c
 void orc_excluded(const orc_ctx *c, uint8_t *out) { memcpy(out, c->excluded, c->total_cells); }
 void orc_set_excluded(orc_ctx *c, const uint8_t *in) { memcpy(c->excluded, in, c->total_cells); }
 
+/* get_cell_log_likelihoods + get_locus_log_likelihoods under caller alpha/beta/mask and a caller exclusion set:
+ * the per-locus half of compute_new_excluded (main.rs:312,343) for a shard of cells (multi-shard host tests). */
+void orc_locus_stats(orc_ctx *c, const double *alpha, const double *beta, const uint8_t *mask,
+                     const uint8_t *new_excluded, double *cmin, double *cmaj, uint64_t *nmin, uint64_t *nmaj,
+                     uint64_t *amin, uint64_t *rmin, uint64_t *amaj, uint64_t *rmaj)
+{
+    uint64_t N = c->total_cells;
+    double *ll = (double *)xcalloc(N, 8), *nl = (double *)xcalloc(N, 8);
+    get_cell_log_likelihoods(c, mask, alpha, beta, c->excluded, ll, NULL, NULL, nl);
+    get_locus_log_likelihoods(c, new_excluded);
+    orc_iter_locus_outputs(c, cmin, cmaj, nmin, nmaj, amin, rmin, amaj, rmaj);
+    free(ll); free(nl);
+}
+
 /* calculate_posteriors — main.rs:228-280 (get_loci_used_for_posterior_calc,
  * main.rs:282-306, returns all-true: quirk Q1) */
 void orc_posteriors(orc_ctx *c, double *posterior, double *doublet_posterior, double *ll_majority,

@@ -105,6 +105,11 @@ void orc_cell_log_likelihoods(orc_ctx *, const double *alpha, const double *beta
                               const uint8_t *mask, double *ll, double *expected_ll,
                               double *loci_used_per_cell);
 
+/* per-locus statistics (main.rs:368-420) of this ctx's cells under caller alpha/beta/mask and exclusion flags */
+void orc_locus_stats(orc_ctx *, const double *alpha, const double *beta, const uint8_t *mask,
+                     const uint8_t *new_excluded, double *contrib_min, double *contrib_maj, uint64_t *cells_min,
+                     uint64_t *cells_maj, uint64_t *alt_min, uint64_t *ref_min, uint64_t *alt_maj, uint64_t *ref_maj);
+
 /* calculate_posteriors (main.rs:228-280) with the ctx's current excluded set. */
 void orc_posteriors(orc_ctx *, double *posterior, double *doublet_posterior,
                     double *ll_majority, double *ll_minority /*[N] each*/);
