@@ -41,6 +41,10 @@ def parse():
                     help="size of the CPU-baseline sample in matrix entries (~1 us/entry/pass on one core)")
     ap.add_argument("--engine", type=int, default=2, choices=[1, 2],
                     help="2 = table-driven tiled passes (default), 1 = CSR/CSC kernels evaluating every entry")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl (= RCCL over xGMI, the real path) or gloo: REHEARSAL ONLY — exchanges staged through the host "
+                         "so that several ranks can share one GPU (--same-device) on a 1-GPU box")
+    ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     ap.add_argument("--no-expected", action="store_true",
                     help="skip the expected_log_likelihood diagnostic column (NOT the reference-equivalent step)")
     return ap.parse_args()
@@ -63,11 +67,16 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: there is no CPU fallback for the hot path")
+    if args.same_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
 
     N, L_total, density = WORKLOADS[args.workload]
     per = (N + world - 1) // world
@@ -79,9 +88,15 @@ def main():
     g.set_option("compute_expected", 0 if args.no_expected else 1)
     g.set_shard(cb, ce)
 
-    def allreduce(t):
+    def allreduce(t, op=None):
         if world > 1:
-            dist.all_reduce(t)
+            kw = {} if op is None else {"op": op}
+            if args.backend == "nccl":
+                dist.all_reduce(t, **kw)
+            else:  # rehearsal: stage through the host
+                h = t.cpu()
+                dist.all_reduce(h, **kw)
+                t.copy_(h)
 
     # ---- ingest (untimed setup): device-side generation, pass-1 exchange, CSR/CSC build
     t_setup = time.time()
@@ -92,7 +107,7 @@ def main():
     g.ingest_finish(4, 4)
     dm = g.dims()
     L = dm.loci_used
-    x_norm = torch.zeros(N, dtype=torch.float64, device=dev)
+    x_norm = torch.zeros(world * per, dtype=torch.float64, device=dev)  # padded: every rank owns `per` slots
     x_locus = torch.zeros(5 * L + 8, dtype=torch.float64, device=dev)
     g.bind_exchange_buffer(ffi.XCHG_NORM, x_norm.data_ptr(), x_norm.numel())
     g.bind_exchange_buffer(ffi.XCHG_LOCUS, x_locus.data_ptr(), x_locus.numel())
@@ -104,9 +119,20 @@ def main():
     allreduce(nnz_t)
     nnz_total = int(nnz_t.item())
 
+    def exchange_norm():
+        # in-place all-gather of the equal-sized contiguous cell slices (half the bytes of a sum all-reduce)
+        if world == 1:
+            return
+        if args.backend == "nccl":
+            dist.all_gather_into_tensor(x_norm, x_norm[rank * per:(rank + 1) * per])
+        else:
+            h = x_norm.cpu()
+            dist.all_gather_into_tensor(h, h[rank * per:(rank + 1) * per].clone())
+            x_norm.copy_(h)
+
     def step():
         g.em_begin()
-        allreduce(x_norm)
+        exchange_norm()
         g.em_threshold(5.0)
         allreduce(x_locus)
         return g.em_finish()
@@ -130,8 +156,7 @@ def main():
     elapsed = time.perf_counter() - t0
     g.set_option("timing", 0)
     el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    allreduce(el, dist.ReduceOp.MAX)
     elapsed = float(el.item())
     ms_per_step = elapsed / args.steps * 1e3
 
@@ -185,7 +210,8 @@ def main():
                        "step": "one EM iteration = alpha/beta + cell LL pass"
                                + ("" if args.no_expected else " (+expected-log-pmf)")
                                + " + exact quartiles + flags + locus pass + locus filter",
-                       "parallelism": f"cells/{world}" if world > 1 else "1 gpu"},
+                       "parallelism": (f"cells/{world}" if world > 1 else "1 gpu")
+                                      + ("" if args.backend == "nccl" else " (gloo host-staged REHEARSAL, not a result)")},
             "em_iters_per_s": args.steps / elapsed,
             "dense_cells_x_loci_per_s": float(N) * float(L) / (elapsed / args.steps),
             "kernels_ms": {"cell_pass": ll_avg, "tile_ll": ti_ms / max(ti_n, 1), "locus_pass": lo_ms / max(lo_n, 1),

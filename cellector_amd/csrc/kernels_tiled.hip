@@ -25,11 +25,12 @@
 #define T_BC 1024       // cells per block == threads per workgroup: one lane per cell
 #define T_THREADS 1024
 #ifndef T_SB
-#define T_SB 2          // cell blocks per workgroup (they share one staged table)
+#define T_SB 4          // cell blocks per workgroup (they share one staged table)
 #endif
 #define T_CAP 6144      // entries of one tile staged per window (12 KB)
 #define T_GROUPS 8
-#define T_HDR 2056      // tile header in u16 units: (T_BC + 1) u32 exclusive offsets, padded to 16 bytes
+#define T_HDR 1088      // tile header in u16 units: 16 x {u32 wave base, u32 wave total} then 1024 x u16 offsets
+                        // (exclusive, relative to the base of the cell's wave: < 64 * T_BL)
 #define T_NP ((T_W * T_BL / 2 + T_THREADS - 1) / T_THREADS)  // double2 table prefetch registers per lane
 // tile entry (u16): bits 0..3 code, 4..12 locus_in_chunk, 13..14 n-1
 #define TE_CODE(e) ((e) & 15u)
@@ -82,8 +83,14 @@ __global__ __launch_bounds__(T_THREADS, 8) void k_tile_ll(uint32_t nb, uint32_t 
                                                           const double *__restrict__ tab, uint64_t npad,
                                                           double *__restrict__ part_ll, double *__restrict__ part_ell)
 {
-    __shared__ double s_tab[T_W * T_BL];      // 54 KB: this chunk's table, [w][locus]
-    __shared__ uint4 s_ent[T_SB][T_CAP / 8];  // staged tile entries (first window of each cell block)
+    // A workgroup owns T_SB consecutive 1024-cell blocks (one lane per cell of each) and one group of locus chunks.
+    // Per chunk the table (54 KB) is staged ONCE and the T_SB tiles are consumed one after the other through a
+    // double-buffered entry window; what is needed next (the next tile's window + header words, the next chunk's
+    // table) travels in registers while the current tile is consumed.  Ablations on cfg4 (profiles/): the
+    // table re-staging traffic from L2 / Infinity Cache and the barrier skeleton weigh as much as the lookups, hence
+    // several cell blocks per staged table and nothing consumed in the step that loaded it.
+    __shared__ double s_tab[T_W * T_BL];
+    __shared__ uint4 s_ent[2][T_CAP / 8];
     const uint32_t tid = threadIdx.x;
     const uint32_t b0 = blockIdx.x * T_SB, g = blockIdx.y;
     const uint32_t j0 = g * cpg, j1 = min(nj, j0 + cpg);
@@ -91,65 +98,70 @@ __global__ __launch_bounds__(T_THREADS, 8) void k_tile_ll(uint32_t nb, uint32_t 
 #pragma unroll
     for (int s = 0; s < T_SB; s++) ll[s] = el[s] = 0.0;
 
-    // registers that carry the NEXT chunk's data while the current one is being consumed
     static_assert(T_NP == 4, "table prefetch registers are written out by hand");
     double2 p_tab0, p_tab1, p_tab2, p_tab3 = make_double2(0.0, 0.0);
-    uint32_t p_beg[T_SB], p_end[T_SB], p_tot[T_SB];
-    uint4 p_ent[T_SB];
-#define TILE_PREFETCH(J)                                                                                        \
+    uint32_t p_rel = 0, p_tot = 0;
+    uint2 p_wb = make_uint2(0, 0);
+    uint4 p_ent = make_uint4(0, 0, 0, 0);
+#define TABLE_PREFETCH(J)                                                                                       \
     do {                                                                                                        \
         const double2 *src__ = reinterpret_cast<const double2 *>(tab + (uint64_t)(J) * (T_W * T_BL));           \
         p_tab0 = src__[tid];                                                                                    \
         p_tab1 = src__[tid + T_THREADS];                                                                        \
         p_tab2 = src__[tid + 2 * T_THREADS];                                                                    \
         if (tid + 3 * T_THREADS < T_W * T_BL / 2) p_tab3 = src__[tid + 3 * T_THREADS];                          \
-        _Pragma("unroll") for (int s = 0; s < T_SB; s++) {                                                     \
-            p_beg[s] = p_end[s] = p_tot[s] = 0;                                                                 \
-            p_ent[s] = make_uint4(0, 0, 0, 0);                                                                  \
-            if (b0 + s < nb) {                                                                                  \
-                const uint16_t *tp__ = tiles + tile_ptr[(uint64_t)(b0 + s) * nj + (J)];                         \
-                const uint32_t *hd__ = reinterpret_cast<const uint32_t *>(tp__);                                \
-                p_beg[s] = hd__[tid];                                                                           \
-                p_end[s] = hd__[tid + 1];                                                                       \
-                p_tot[s] = hd__[T_BC];                                                                          \
-                /* first window; reading past a short tile stays inside the allocation (next tile / tail pad) */ \
-                if (tid < T_CAP / 8) p_ent[s] = reinterpret_cast<const uint4 *>(tp__ + T_HDR)[tid];             \
-            }                                                                                                   \
+    } while (0)
+#define TILE_PREFETCH(J, S)                                                                                     \
+    do {                                                                                                        \
+        p_tot = 0; p_rel = 0; p_wb = make_uint2(0, 0);                                                          \
+        if (b0 + (S) < nb) {                                                                                    \
+            const uint64_t t__ = (uint64_t)(b0 + (S)) * nj + (J);                                               \
+            const uint64_t o__ = tile_ptr[t__];                                                                 \
+            p_tot = (uint32_t)(tile_ptr[t__ + 1] - o__) - T_HDR; /* entries, padded to a multiple of 8 */       \
+            p_wb = reinterpret_cast<const uint2 *>(tiles + o__)[tid >> 6]; /* wave base, wave total */          \
+            p_rel = (tiles + o__ + 64)[tid];            /* consumed one step later: the loads stay in flight */ \
+            if (tid < min(p_tot, (uint32_t)T_CAP) / 8)                                                          \
+                p_ent = reinterpret_cast<const uint4 *>(tiles + o__ + T_HDR)[tid];                              \
         }                                                                                                       \
     } while (0)
 
-    if (j0 < j1) TILE_PREFETCH(j0);
+    if (j0 < j1) {
+        TABLE_PREFETCH(j0);
+        TILE_PREFETCH(j0, 0);
+    }
     for (uint32_t j = j0; j < j1; j++) {
-        __syncthreads();  // everybody is done with the previous chunk's LDS contents
+        __syncthreads();  // every wave is done with the previous chunk's table
         {
             double2 *dst = reinterpret_cast<double2 *>(s_tab);
             dst[tid] = p_tab0;
             dst[tid + T_THREADS] = p_tab1;
             dst[tid + 2 * T_THREADS] = p_tab2;
             if (tid + 3 * T_THREADS < T_W * T_BL / 2) dst[tid + 3 * T_THREADS] = p_tab3;
-#pragma unroll
-            for (int s = 0; s < T_SB; s++)
-                if (tid < T_CAP / 8) s_ent[s][tid] = p_ent[s];
         }
-        uint32_t my_s[T_SB], my_e[T_SB], total[T_SB];
-#pragma unroll
-        for (int s = 0; s < T_SB; s++) { my_s[s] = p_beg[s]; my_e[s] = p_end[s]; total[s] = p_tot[s]; }
-        __syncthreads();
-        if (j + 1 < j1) TILE_PREFETCH(j + 1);  // in flight during the compute below
+        if (j + 1 < j1) TABLE_PREFETCH(j + 1);
 #pragma unroll
         for (int s = 0; s < T_SB; s++) {
-            const uint16_t *se = reinterpret_cast<const uint16_t *>(s_ent[s]);
+            uint4 *win = s_ent[s & 1];
+            uint32_t nxt = (uint32_t)__shfl_down((int)p_rel, 1, 64);  // the next cell's offset = this cell's end
+            if ((tid & 63) == 63) nxt = p_wb.y;
+            const uint32_t my_s = p_wb.x + p_rel, my_e = p_wb.x + nxt, total = p_tot;
+            if (tid < min(total, (uint32_t)T_CAP) / 8) win[tid] = p_ent;
+            // the next tile's loads go out BEFORE the barrier: the barrier wait is latency-hiding time too
+            if (s + 1 < T_SB) TILE_PREFETCH(j, s + 1);
+            else if (j + 1 < j1) TILE_PREFETCH(j + 1, 0);
+            __syncthreads();  // window s (and, for s == 0, the table) visible; window s-2 no longer read by anybody
+            const uint16_t *se = reinterpret_cast<const uint16_t *>(win);
             double a_ll = ll[s], a_el = el[s];
-            for (uint32_t w0 = 0; w0 < total[s]; w0 += T_CAP) {  // total is uniform over the workgroup
-                const uint32_t n_in = min((uint32_t)T_CAP, total[s] - w0);
+            for (uint32_t w0 = 0; w0 < total; w0 += T_CAP) {  // total is uniform over the workgroup
+                const uint32_t n_in = min((uint32_t)T_CAP, total - w0);
                 if (w0) {  // a tile larger than one window (dense data): stage the next window synchronously
                     const uint16_t *tp = tiles + tile_ptr[(uint64_t)(b0 + s) * nj + j];
                     const uint4 *ep = reinterpret_cast<const uint4 *>(tp + T_HDR);
                     __syncthreads();
-                    for (uint32_t i = tid; i < ((n_in + 7u) >> 3); i += T_THREADS) s_ent[s][i] = ep[(w0 >> 3) + i];
+                    for (uint32_t i = tid; i < (n_in >> 3); i += T_THREADS) win[i] = ep[(w0 >> 3) + i];
                     __syncthreads();
                 }
-                const uint32_t klo = max(my_s[s], w0), khi = min(my_e[s], w0 + n_in);
+                const uint32_t klo = max(my_s, w0), khi = min(my_e, w0 + n_in);
                 for (uint32_t k = klo; k < khi; ++k) {
                     const uint32_t e = se[k - w0], loc = TE_LOC(e);
                     a_ll += s_tab[TE_CODE(e) * T_BL + loc];
@@ -161,6 +173,7 @@ __global__ __launch_bounds__(T_THREADS, 8) void k_tile_ll(uint32_t nb, uint32_t 
         }
     }
 #undef TILE_PREFETCH
+#undef TABLE_PREFETCH
 #pragma unroll
     for (int s = 0; s < T_SB; s++) {
         if (b0 + s < nb) {
@@ -601,8 +614,11 @@ __global__ __launch_bounds__(T_BC) void k_tile_build(uint64_t nloc, uint32_t nj,
     }
     uint16_t *tp = tiles + tile_elems[t];
     uint32_t *hd = reinterpret_cast<uint32_t *>(tp);
-    hd[cl] = woff + inc - reg;          // exclusive offset of this cell's segment
-    if (cl == 0) hd[T_BC] = total;
+    if (lane == 0) {
+        hd[2 * wv] = woff;          // first entry of this wave's cells
+        hd[2 * wv + 1] = s_ws[wv];  // entries of this wave's cells
+    }
+    tp[64 + cl] = (uint16_t)(inc - reg);  // exclusive offset inside the wave: < 64 * T_BL
     uint16_t *dst = tp + T_HDR + (woff + inc - reg);
     for (uint64_t i = lo; i < hi; i++) {
         const uint64_t e = csr_ent[i];
@@ -610,10 +626,8 @@ __global__ __launch_bounds__(T_BC) void k_tile_build(uint64_t nloc, uint32_t nj,
             *dst++ = (uint16_t)(((ENT_ALT(e) + ENT_REF(e) - 1u) << 13) | ((ENT_IDX(e) - j * T_BL) << 4) | ent_code(e));
     }
     // zero the padding so that staged vectors never carry garbage
-    if (cl == 0) {
+    if (cl == 0)
         for (uint32_t k = total; k < ((total + 7u) & ~7u); k++) tp[T_HDR + k] = 0;
-        for (uint32_t k = 2 * (T_BC + 1); k < T_HDR; k++) tp[k] = 0;
-    }
 }
 
 // wave per row/column: count entries that are NOT regular (FILL = false) or copy them in order (FILL = true)

@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcellector_hip.so")
+LIB_PATH = os.environ.get("CELLECTOR_HIP_LIB") or os.path.join(_HERE, "libcellector_hip.so")
 
 XCHG_PASS1, XCHG_NORM, XCHG_LOCUS = 0, 1, 2
 K_CELL_LL, K_LOCUS_STATS, K_SELECT, K_POSTERIOR, K_TILE_LL = 0, 1, 2, 3, 4

@@ -60,10 +60,10 @@ class HipShardEngine:
         self.g.ingest_mtx(alt_path, ref_path)
         return self.buf[XCHG_PASS1]
 
-    def ingest_finish(self, min_alt, min_ref):
+    def ingest_finish(self, min_alt, min_ref, norm_len=0):
         self.g.ingest_finish(min_alt, min_ref)
         d = self.g.dims()
-        self._bind(XCHG_NORM, d.total_cells)
+        self._bind(XCHG_NORM, max(d.total_cells, norm_len))  # padded to world * cells-per-rank for the all-gather
         self._bind(XCHG_LOCUS, 5 * d.loci_used + 8)
         return d
 
@@ -96,16 +96,30 @@ class ShardedCellector:
         if self.dist is not None and self.world > 1:
             self.dist.all_reduce(t)  # SUM
 
+    def _exchange_norm(self, t):
+        """Every rank contributes its own cells' slice.  Shards are equal-sized contiguous ranges, so this is an
+        in-place all-gather (recv = whole buffer, send = this rank's slice of it); half the bytes of the sum
+        all-reduce it replaces.  Falls back to the all-reduce (other slices are zero) if the buffer is unpadded."""
+        if self.dist is None or self.world == 1:
+            return
+        per = (self.total_cells + self.world - 1) // self.world
+        if t.numel() >= self.world * per:
+            self.dist.all_gather_into_tensor(t[: self.world * per], t[self.rank * per:(self.rank + 1) * per])
+        else:
+            self.dist.all_reduce(t)
+
     def load(self, ingest, total_cells, min_alt=4, min_ref=4):
         """ingest(engine) -> PASS1 tensor; e.g. lambda e: e.ingest_synthetic(L, N, d, seed=4)."""
         cb, ce = shard_range(total_cells, self.rank, self.world)
+        self.total_cells = total_cells
         self.e.set_shard(cb, ce)
         self._allreduce(ingest(self.e))
-        self.dims = self.e.ingest_finish(min_alt, min_ref)
+        per = (total_cells + self.world - 1) // self.world
+        self.dims = self.e.ingest_finish(min_alt, min_ref, self.world * per)
         return self.dims
 
     def em_iteration(self, iqr_multiple=5.0):
-        self._allreduce(self.e.em_begin())
+        self._exchange_norm(self.e.em_begin())
         self._allreduce(self.e.em_threshold(iqr_multiple))
         s = self.e.em_finish()
         self.summaries.append(s)

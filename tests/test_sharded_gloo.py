@@ -40,7 +40,7 @@ class OracleShardEngine:
         self.pass1 = self.torch.from_numpy(p1.reshape(-1).copy())
         return self.pass1
 
-    def ingest_finish(self, min_alt, min_ref):
+    def ingest_finish(self, min_alt, min_ref, norm_len=0):
         p1 = self.pass1.numpy().reshape(5, self.TL)
         used = (p1[0] >= min_ref) & (p1[1] >= min_alt)
         self.locus_ids = np.nonzero(used)[0]
@@ -62,7 +62,7 @@ class OracleShardEngine:
         self.mask = np.ones(self.L, np.uint8)
         self.flags = np.zeros(nloc, np.uint8)
         self.locus = self.torch.zeros(5 * self.L + 8, dtype=self.torch.float64)
-        self.norm = self.torch.zeros(self.N, dtype=self.torch.float64)
+        self.norm = self.torch.zeros(max(self.N, norm_len), dtype=self.torch.float64)
         return types.SimpleNamespace(total_cells=self.N, total_loci=self.TL, loci_used=self.L, cell_begin=self.cb,
                                      cell_end=self.ce, nnz_used=len(li))
 
@@ -78,7 +78,7 @@ class OracleShardEngine:
         return self.norm
 
     def em_threshold(self, iqr):
-        x = self.norm.numpy()
+        x = self.norm.numpy()[:self.N]
         self.median = self.ob.median(x)
         q1, q3 = self.ob.quantile(x, 0.25), self.ob.quantile(x, 0.75)
         self.iqr = q3 - q1
