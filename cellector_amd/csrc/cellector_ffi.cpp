@@ -213,10 +213,16 @@ cellector_status cellector_ingest_mtx(cellector_ctx *c, const char *alt_path, co
 {
     if (!c) return CELLECTOR_EINVAL;
     REQUIRE(c, alt_path && ref_path, "null path");
-    HostCoo coo;
-    CHK(read_mtx_pair(c, alt_path, ref_path, &coo));
-    return cellector_ingest_coo(c, coo.total_loci, coo.total_cells, coo.locus.size(), coo.locus.data(),
-                                coo.cell.data(), coo.alt.data(), coo.ref.data());
+    MtxInput *in = nullptr;
+    uint64_t tl = 0, tc = 0;
+    CHK(mtx_input_open(c, alt_path, ref_path, &in, &tl, &tc));
+    cellector_status s = begin_ingest(c, tl, tc);
+    if (s == CELLECTOR_OK) s = ingest_stage_mtx_device(c, in);  // tokenised and converted on the GPU
+    mtx_input_close(in);
+    CHK(s);
+    CHK(ingest_pass1(c));
+    c->state = cellector_ctx::ST_STAGED;
+    return CELLECTOR_OK;
 }
 
 cellector_status cellector_ingest_synthetic(cellector_ctx *c, uint64_t total_loci, uint64_t total_cells,

@@ -192,9 +192,9 @@ cellector_status tiled_cell_pass(cellector_ctx *c, const double2 *ab, double *no
 cellector_status tiled_locus_pass(cellector_ctx *c);
 cellector_status tiled_masked_update(cellector_ctx *c);
 cellector_status tiled_posteriors(cellector_ctx *c, double mf0, double lp_min, double lp_maj, double lp_dbl);
-// host mtx reader (mtx_reader.cpp)
-struct HostCoo {
-    uint64_t total_loci = 0, total_cells = 0;
-    std::vector<uint32_t> locus, cell, alt, ref;
-};
-cellector_status read_mtx_pair(const cellector_ctx *c, const char *alt_path, const char *ref_path, HostCoo *out);
+// device-side mtx text parse (kernels_parse.hip)
+struct MtxInput;
+cellector_status mtx_input_open(const cellector_ctx *c, const char *alt_path, const char *ref_path, MtxInput **out,
+                                uint64_t *total_loci, uint64_t *total_cells);
+void mtx_input_close(MtxInput *in);
+cellector_status ingest_stage_mtx_device(cellector_ctx *c, MtxInput *in);

@@ -1,0 +1,396 @@
+// Device-side parse of the vartrix alt.mtx / ref.mtx text (rows A1 and f2 of the scope table).
+//
+// The host only brings bytes (mmap for plain files, zlib inflate for ".gz", multi-member) and reads the three header
+// lines; the data lines are tokenised and converted on the GPU:
+//   k_nl_count / k_nl_fill   line starts: every thread looks at 16 bytes, per-thread newline counts are scanned, the
+//                            positions are written in order;
+//   k_parse_lines            one thread per line: split_whitespace + parse::<usize>() of the tokens the reference reads
+//                            (load_data.rs:190-204): alt file tokens 0,1,2 (locus, cell, alt count), ref file token 2 only
+//                            (its indices are never read); any failure records the smallest offending line;
+//   k_pair_check / k_pair_fill   zip the two files (shorter one wins, like izip!), range checks, this shard's cell range,
+//                            ordered compaction into the staged COO (locus u32, cell_local u32, alt u16, ref u16).
+// The text contract is the reference's; errors come back as CELLECTOR_EPARSE / CELLECTOR_EINVAL with the line number.
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+#include <zlib.h>
+
+#include "ctx.h"
+#include "device_math.h"
+
+#define PB 256
+
+__device__ __forceinline__ bool is_ws(uint8_t ch)
+{
+    return ch == ' ' || ch == '\t' || ch == '\r' || ch == '\n' || ch == '\f' || ch == '\v';
+}
+
+// ---- line starts ----------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t newline_mask16(const uint8_t *__restrict__ text, uint64_t n, uint64_t base)
+{
+    uint32_t m = 0;
+    if (base + 16 <= n) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(text + base);
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+#pragma unroll
+            for (int b = 0; b < 4; b++)
+                if (((w[q] >> (8 * b)) & 0xffu) == '\n') m |= 1u << (4 * q + b);
+    } else {
+        for (uint64_t i = base; i < n; i++)
+            if (text[i] == '\n') m |= 1u << (uint32_t)(i - base);
+    }
+    return m;
+}
+
+__global__ __launch_bounds__(PB) void k_nl_count(const uint8_t *__restrict__ text, uint64_t n, uint64_t *__restrict__ cnt)
+{
+    const uint64_t t = (uint64_t)blockIdx.x * PB + threadIdx.x;
+    const uint64_t base = t * 16;
+    if (base >= n) return;
+    cnt[t] = __popc(newline_mask16(text, n, base));
+}
+
+// line_start[k] = byte after the k-th newline (line 0 starts at 0 and is written by the caller's memset)
+__global__ __launch_bounds__(PB) void k_nl_fill(const uint8_t *__restrict__ text, uint64_t n,
+                                                const uint64_t *__restrict__ off, uint64_t *__restrict__ line_start)
+{
+    const uint64_t t = (uint64_t)blockIdx.x * PB + threadIdx.x;
+    const uint64_t base = t * 16;
+    if (base >= n) return;
+    uint32_t m = newline_mask16(text, n, base);
+    uint64_t k = off[t];
+    while (m) {
+        const int b = __ffs((int)m) - 1;
+        m &= m - 1;
+        line_start[1 + k++] = base + b + 1;
+    }
+}
+
+// ---- tokens ---------------------------------------------------------------------------------------------------
+// parse token `idx` of [p, e) as an unsigned integer (optional leading '+'); false on missing / malformed / > 2^32-1
+__device__ bool token_u32(const uint8_t *__restrict__ p, const uint8_t *__restrict__ e, int first_idx, int n_tok,
+                          uint32_t *out)
+{
+    int t = 0;
+    while (true) {
+        while (p < e && is_ws(*p)) p++;
+        if (p >= e) return false;
+        const uint8_t *s = p;
+        while (p < e && !is_ws(*p)) p++;
+        if (t >= first_idx) {
+            if (*s == '+') s++;
+            if (s == p) return false;
+            uint64_t v = 0;
+            for (; s < p; s++) {
+                if (*s < '0' || *s > '9') return false;
+                v = v * 10 + (uint64_t)(*s - '0');
+                if (v > 0xffffffffull) return false;
+            }
+            out[t - first_idx] = (uint32_t)v;
+            if (t - first_idx + 1 == n_tok) return true;
+        }
+        t++;
+    }
+}
+
+// ALT file: tokens 0,1,2 -> (locus1, cell1, count); REF file: token 2 -> count
+template <bool ALT>
+__global__ __launch_bounds__(PB) void k_parse_lines(const uint8_t *__restrict__ text, uint64_t n, uint64_t n_lines,
+                                                    const uint64_t *__restrict__ line_start, uint32_t *__restrict__ o0,
+                                                    uint32_t *__restrict__ o1, uint32_t *__restrict__ o2,
+                                                    unsigned long long *__restrict__ first_bad)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * PB + threadIdx.x;
+    if (i >= n_lines) return;
+    const uint8_t *p = text + line_start[i];
+    const uint8_t *e = text + (i + 1 < n_lines ? line_start[i + 1] : n);
+    uint32_t v[3] = {0, 0, 0};
+    const bool ok = ALT ? token_u32(p, e, 0, 3, v) : token_u32(p, e, 2, 1, v);
+    if (!ok) {
+        atomicMin(first_bad, (unsigned long long)i);
+        return;
+    }
+    if (ALT) { o0[i] = v[0]; o1[i] = v[1]; o2[i] = v[2]; } else o2[i] = v[0];
+}
+
+// ---- zip, validate, shard filter ------------------------------------------------------------------------------
+enum { PE_NONE = 0, PE_INDEX0 = 1, PE_LOCUS = 2, PE_CELL = 3, PE_COUNT = 4 };
+
+__global__ __launch_bounds__(PB) void k_pair_check(uint64_t n, const uint32_t *__restrict__ l1, const uint32_t *__restrict__ c1,
+                                                   const uint32_t *__restrict__ a, const uint32_t *__restrict__ r,
+                                                   uint64_t total_loci, uint64_t total_cells, uint64_t cb, uint64_t ce,
+                                                   uint64_t *__restrict__ keep, unsigned long long *__restrict__ first_bad,
+                                                   uint32_t *__restrict__ bad_kind, uint32_t *__restrict__ unsorted)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * PB + threadIdx.x;
+    if (i > n) return;
+    if (i == n) { keep[i] = 0; return; }
+    uint32_t kind = PE_NONE;
+    if (l1[i] == 0 || c1[i] == 0) kind = PE_INDEX0;          // `tok - 1` underflows in the reference
+    else if (l1[i] > total_loci) kind = PE_LOCUS;
+    else if (c1[i] > total_cells) kind = PE_CELL;
+    else if (a[i] > CELLECTOR_MAX_COUNT || r[i] > CELLECTOR_MAX_COUNT) kind = PE_COUNT;
+    if (kind != PE_NONE) {
+        if (atomicMin(first_bad, (unsigned long long)i) > i) *bad_kind = kind;  // best effort: kind of the smallest seen
+        keep[i] = 0;
+        return;
+    }
+    const uint64_t c0 = c1[i] - 1;
+    const bool mine = c0 >= cb && c0 < ce;
+    keep[i] = mine ? 1 : 0;
+    if (i + 1 < n && l1[i + 1] < l1[i]) *unsorted = 1;  // file order not locus-major (all entries, a superset check)
+}
+
+__global__ __launch_bounds__(PB) void k_pair_fill(uint64_t n, const uint32_t *__restrict__ l1, const uint32_t *__restrict__ c1,
+                                                  const uint32_t *__restrict__ a, const uint32_t *__restrict__ r, uint64_t cb,
+                                                  uint64_t ce, const uint64_t *__restrict__ pos, uint32_t *__restrict__ o_locus,
+                                                  uint32_t *__restrict__ o_cell, uint16_t *__restrict__ o_alt,
+                                                  uint16_t *__restrict__ o_ref)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * PB + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t c0 = (uint64_t)c1[i] - 1;
+    if (c1[i] == 0 || c0 < cb || c0 >= ce) return;
+    const uint64_t p = pos[i];
+    o_locus[p] = l1[i] - 1;
+    o_cell[p] = (uint32_t)(c0 - cb);
+    o_alt[p] = (uint16_t)a[i];
+    o_ref[p] = (uint16_t)r[i];
+}
+
+// ===============================================================================================================
+namespace {
+
+struct FileBytes {
+    const uint8_t *data = nullptr;
+    size_t size = 0;
+    void *map = nullptr;
+    size_t map_len = 0;
+    int fd = -1;
+    std::vector<uint8_t> owned;
+    ~FileBytes()
+    {
+        if (map) munmap(map, map_len);
+        if (fd >= 0) close(fd);
+    }
+};
+
+// reader (load_data.rs:240-251): ".gz" by extension (multi-member), plain otherwise
+bool load_bytes(const char *path, FileBytes *fb)
+{
+    const size_t n = strlen(path);
+    if (n >= 3 && strcmp(path + n - 3, ".gz") == 0) {
+        gzFile gz = gzopen(path, "rb");
+        if (!gz) return false;
+        gzbuffer(gz, 1 << 20);
+        size_t cap = 1 << 24, len = 0;
+        fb->owned.resize(cap);
+        for (;;) {
+            if (len == cap) fb->owned.resize(cap *= 2);
+            const int got = gzread(gz, fb->owned.data() + len, (unsigned)std::min<size_t>(cap - len, 1u << 30));
+            if (got <= 0) break;
+            len += (size_t)got;
+        }
+        gzclose(gz);
+        fb->data = fb->owned.data();
+        fb->size = len;
+        return true;
+    }
+    fb->fd = open(path, O_RDONLY);
+    if (fb->fd < 0) return false;
+    struct stat st;
+    if (fstat(fb->fd, &st) != 0) return false;
+    fb->size = (size_t)st.st_size;
+    if (fb->size) {
+        fb->map = mmap(nullptr, fb->size, PROT_READ, MAP_PRIVATE, fb->fd, 0);
+        if (fb->map == MAP_FAILED) { fb->map = nullptr; return false; }
+        fb->map_len = fb->size;
+        madvise(fb->map, fb->size, MADV_SEQUENTIAL);
+        fb->data = (const uint8_t *)fb->map;
+    }
+    return true;
+}
+
+// consume_mtx_header (load_data.rs:206-223): exactly three lines; returns the offset of the first data byte
+size_t skip_header(const FileBytes &fb, std::string *third)
+{
+    size_t pos = 0;
+    for (int x = 0; x < 3; x++) {
+        const void *nl = pos < fb.size ? memchr(fb.data + pos, '\n', fb.size - pos) : nullptr;
+        const size_t end = nl ? (size_t)((const uint8_t *)nl - fb.data) : fb.size;
+        if (x == 2 && third) third->assign((const char *)fb.data + pos, end - pos);
+        pos = nl ? end + 1 : fb.size;
+    }
+    return pos;
+}
+
+bool host_tok_u64(const std::string &s, int idx, uint64_t *out)
+{
+    size_t p = 0;
+    for (int t = 0;; t++) {
+        while (p < s.size() && isspace((unsigned char)s[p])) p++;
+        if (p >= s.size()) return false;
+        size_t b = p;
+        while (p < s.size() && !isspace((unsigned char)s[p])) p++;
+        if (t == idx) {
+            if (s[b] == '+') b++;
+            if (b == p) return false;
+            uint64_t v = 0;
+            for (; b < p; b++) {
+                if (s[b] < '0' || s[b] > '9') return false;
+                v = v * 10 + (uint64_t)(s[b] - '0');
+            }
+            *out = v;
+            return true;
+        }
+    }
+}
+
+struct DevText {
+    uint8_t *text = nullptr;
+    uint64_t n = 0, n_lines = 0;
+    uint64_t *line_start = nullptr;
+};
+
+inline unsigned pgrid(uint64_t n) { return (unsigned)((n + PB - 1) / PB ? (n + PB - 1) / PB : 1); }
+
+cellector_status upload_and_split(cellector_ctx *c, const FileBytes &fb, size_t data_off, DevText *dt)
+{
+    dt->n = fb.size - data_off;
+    // a final line without '\n' still counts (BufRead::lines); normalise by treating the end of data as a terminator
+    CHK(dev_alloc(c, &dt->text, dt->n + 16));
+    HIPCHK(c, hipMemsetAsync(dt->text + dt->n, '\n', 16, c->stream));
+    const size_t piece = 1ull << 30;
+    for (size_t o = 0; o < dt->n; o += piece)
+        HIPCHK(c, hipMemcpy(dt->text + o, fb.data + data_off + o, std::min(piece, (size_t)dt->n - o), hipMemcpyHostToDevice));
+    const bool unterminated = dt->n > 0 && fb.data[fb.size - 1] != '\n';
+    const uint64_t n_scan = dt->n + (unterminated ? 1 : 0);  // include one padding '\n' as the terminator
+    const uint64_t nthreads = (n_scan + 15) / 16;
+    uint64_t *cnt = nullptr;
+    CHK(dev_alloc(c, &cnt, nthreads + 1));
+    HIPCHK(c, hipMemsetAsync(cnt, 0, (nthreads + 1) * 8, c->stream));
+    if (nthreads) hipLaunchKernelGGL(k_nl_count, dim3(pgrid(nthreads)), dim3(PB), 0, c->stream, dt->text, n_scan, cnt);
+    HIPCHK(c, hipGetLastError());
+    uint64_t n_nl = 0;
+    CHK(dev_exclusive_scan_u64(c, cnt, nthreads + 1, &n_nl));
+    dt->n_lines = n_nl;  // every line is terminated now
+    CHK(dev_alloc(c, &dt->line_start, n_nl + 1));
+    HIPCHK(c, hipMemsetAsync(dt->line_start, 0, 8, c->stream));
+    if (nthreads) hipLaunchKernelGGL(k_nl_fill, dim3(pgrid(nthreads)), dim3(PB), 0, c->stream, dt->text, n_scan, cnt, dt->line_start);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    dev_free(cnt);
+    dt->n = n_scan;
+    return CELLECTOR_OK;
+}
+
+}  // namespace
+
+struct MtxInput {
+    FileBytes fa, fr;
+    size_t off_a = 0, off_r = 0;
+    uint64_t total_loci = 0, total_cells = 0;
+};
+
+// open both files (bytes only) and read the dims from the REF file's third header line (load_data.rs:216-220)
+cellector_status mtx_input_open(const cellector_ctx *c, const char *alt_path, const char *ref_path, MtxInput **out,
+                                uint64_t *total_loci, uint64_t *total_cells)
+{
+    MtxInput *in = new (std::nothrow) MtxInput();
+    if (!in) return ctx_fail(c, CELLECTOR_ENOMEM, "out of host memory");
+    cellector_status st = CELLECTOR_OK;
+    std::string third;
+    if (!load_bytes(alt_path, &in->fa)) st = ctx_fail(c, CELLECTOR_EIO, "couldn't open file %s", alt_path);
+    else if (!load_bytes(ref_path, &in->fr)) st = ctx_fail(c, CELLECTOR_EIO, "couldn't open file %s", ref_path);
+    else {
+        in->off_a = skip_header(in->fa, nullptr);
+        in->off_r = skip_header(in->fr, &third);
+        if (!host_tok_u64(third, 0, &in->total_loci) || !host_tok_u64(third, 1, &in->total_cells))
+            st = ctx_fail(c, CELLECTOR_EPARSE, "cannot parse the matrix market size line of %s", ref_path);
+    }
+    if (st != CELLECTOR_OK) {
+        delete in;
+        return st;
+    }
+    *total_loci = in->total_loci;
+    *total_cells = in->total_cells;
+    *out = in;
+    return CELLECTOR_OK;
+}
+
+void mtx_input_close(MtxInput *in) { delete in; }
+
+// Stage this shard's entries of the alt/ref pair on the device; dims / shard range must already be set on the ctx.
+cellector_status ingest_stage_mtx_device(cellector_ctx *c, MtxInput *in)
+{
+    FileBytes &fa = in->fa, &fr = in->fr;
+    const size_t off_a = in->off_a, off_r = in->off_r;
+    DevText ta, tr;
+    cellector_status st = upload_and_split(c, fa, off_a, &ta);
+    if (st == CELLECTOR_OK) st = upload_and_split(c, fr, off_r, &tr);
+    uint32_t *l1 = nullptr, *c1 = nullptr, *a = nullptr, *r = nullptr, *flags = nullptr;
+    unsigned long long *bad = nullptr;
+    uint64_t *keep = nullptr;
+    auto cleanup = [&]() {
+        dev_free(ta.text); dev_free(ta.line_start); dev_free(tr.text); dev_free(tr.line_start);
+        dev_free(l1); dev_free(c1); dev_free(a); dev_free(r); dev_free(flags); dev_free(bad); dev_free(keep);
+    };
+#define PCHK(expr)                     \
+    do {                               \
+        cellector_status s__ = (expr); \
+        if (s__ != CELLECTOR_OK) {     \
+            cleanup();                 \
+            return s__;                \
+        }                              \
+    } while (0)
+    PCHK(st);
+    const uint64_t n = std::min(ta.n_lines, tr.n_lines);  // izip!: stops at the shorter file
+    PCHK(dev_alloc(c, &l1, n)); PCHK(dev_alloc(c, &c1, n)); PCHK(dev_alloc(c, &a, n)); PCHK(dev_alloc(c, &r, n));
+    PCHK(dev_alloc(c, &bad, 2)); PCHK(dev_alloc(c, &flags, 4)); PCHK(dev_alloc(c, &keep, n + 1));
+    unsigned long long h_bad[2] = {~0ull, ~0ull};
+    uint32_t h_flags[4] = {0, 0, 0, 0};
+    hipError_t e = hipMemcpy(bad, h_bad, sizeof h_bad, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(flags, h_flags, sizeof h_flags, hipMemcpyHostToDevice);
+    if (e != hipSuccess) { cleanup(); return ctx_fail(c, CELLECTOR_EDEVICE, "parse: %s", hipGetErrorString(e)); }
+    if (n) {
+        hipLaunchKernelGGL(k_parse_lines<true>, dim3(pgrid(n)), dim3(PB), 0, c->stream, ta.text, ta.n, n, ta.line_start, l1, c1,
+                           a, bad);
+        hipLaunchKernelGGL(k_parse_lines<false>, dim3(pgrid(n)), dim3(PB), 0, c->stream, tr.text, tr.n, n, tr.line_start,
+                           (uint32_t *)nullptr, (uint32_t *)nullptr, r, bad);
+    }
+    e = hipMemcpy(h_bad, bad, sizeof h_bad, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) { cleanup(); return ctx_fail(c, CELLECTOR_EDEVICE, "parse: %s", hipGetErrorString(e)); }
+    if (h_bad[0] != ~0ull) {
+        cleanup();
+        return ctx_fail(c, CELLECTOR_EPARSE, "cannot parse mtx entry %llu (line %llu of the data section)", h_bad[0], h_bad[0] + 1);
+    }
+    hipLaunchKernelGGL(k_pair_check, dim3(pgrid(n + 1)), dim3(PB), 0, c->stream, n, l1, c1, a, r, c->total_loci, c->total_cells,
+                       c->cell_begin, c->cell_end, keep, bad + 1, flags, flags + 1);
+    e = hipMemcpy(h_bad, bad, sizeof h_bad, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(h_flags, flags, sizeof h_flags, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) { cleanup(); return ctx_fail(c, CELLECTOR_EDEVICE, "parse: %s", hipGetErrorString(e)); }
+    if (h_bad[1] != ~0ull) {
+        cleanup();
+        static const char *what[] = {"", "index 0 (indices are 1-based)", "locus index out of range", "cell index out of range",
+                                     "count above 65535 not supported"};
+        return ctx_fail(c, CELLECTOR_EINVAL, "mtx entry %llu: %s", h_bad[1], what[h_flags[0] <= 4 ? h_flags[0] : 0]);
+    }
+    uint64_t kept = 0;
+    PCHK(dev_exclusive_scan_u64(c, keep, n + 1, &kept));
+    c->coo_n = kept;
+    c->coo_sorted = h_flags[1] == 0;
+    PCHK(dev_alloc(c, &c->coo_locus, kept)); PCHK(dev_alloc(c, &c->coo_cell, kept));
+    PCHK(dev_alloc(c, &c->coo_alt, kept)); PCHK(dev_alloc(c, &c->coo_ref, kept));
+    if (n)
+        hipLaunchKernelGGL(k_pair_fill, dim3(pgrid(n)), dim3(PB), 0, c->stream, n, l1, c1, a, r, c->cell_begin, c->cell_end, keep,
+                           c->coo_locus, c->coo_cell, c->coo_alt, c->coo_ref);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    cleanup();
+    if (e != hipSuccess) return ctx_fail(c, CELLECTOR_EDEVICE, "parse: %s", hipGetErrorString(e));
+#undef PCHK
+    return CELLECTOR_OK;
+}

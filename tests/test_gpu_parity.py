@@ -336,3 +336,60 @@ def test_medium_matrix_properties_and_parity(mods):
     cls = mods["synth"].cell_classes(N, seed=4, minority_fraction=0.05)
     assert (ex[cls == 1] == 1).mean() > 0.95 and (ex[cls == 0] == 1).mean() < 0.01
     g.close()
+
+
+def test_mtx_text_contract_on_device(mods, tmp_path):
+    """The device tokeniser honours the reference's text contract (quirk Q11 and friends): dims from the REF header,
+    indices from the ALT file only, nnz ignored, zip stops at the shorter file, CRLF / '+' / missing final newline
+    accepted like split_whitespace + parse::<usize>(), anything else is a parse error with the entry number."""
+    alt, ref = tmp_path / "alt.mtx", tmp_path / "ref.mtx"
+    alt.write_text("%%MatrixMarket\n%\n99 99 99\n1 1 2\r\n1 2 +1\n2 1 0\n  2   2 3  \n2\t3\t1\n2 3 7")  # last line unterminated
+    ref.write_text("%%MatrixMarket\n%\n2 3 0\nx y 1\n8 8 0\n9 9 4\n1 1 1\n7 7 2\n")                    # indices nonsense, one line shorter
+    g = mods["Cellector"](0)
+    g.load_mtx(str(alt), str(ref), 1, 1)
+    o = mods["ob"].Oracle.from_mtx(str(alt), str(ref), 1, 1)
+    d = g.dims()
+    assert (d.total_loci, d.total_cells, d.loci_used, d.nnz_used) == (2, 3, o.loci_used, o.nnz) == (2, 3, 2, 5)
+    assert np.array_equal(g.locus_counts(), o.locus_counts())
+    rp, ent = g.csr_rows(0, 3)
+    assert rp.tolist() == o.row_ptr().tolist() == [0, 2, 4, 5]
+    g.close()
+    cases = {
+        "float": "1 1 1.0\n", "blank": "1 1 1\n\n1 2 1\n", "two_tokens": "1 1\n", "negative": "1 -1 1\n",
+        "index0": "0 1 1\n", "locus_range": "3 1 1\n", "cell_range": "1 4 1\n", "count_range": "1 1 70000\n",
+    }
+    for name, body in cases.items():
+        bad = tmp_path / f"{name}.mtx"
+        bad.write_text("%%MatrixMarket\n%\n2 3 0\n" + body)
+        g = mods["Cellector"](0)
+        with pytest.raises(mods["ffi"].CellectorError) as ei:
+            g.load_mtx(str(bad), str(bad), 1, 1)
+        assert ei.value.status in (1, 3) and "entry" in str(ei.value), name
+        g.close()
+    hdr = tmp_path / "hdr.mtx"
+    hdr.write_text("%%MatrixMarket\n%\n")
+    g = mods["Cellector"](0)
+    with pytest.raises(mods["ffi"].CellectorError, match="size line"):
+        g.load_mtx(str(hdr), str(hdr), 1, 1)
+    g.close()
+
+
+def test_sharded_mtx_ingest_equals_coo_ingest(mods, tmp_path):
+    L, N = 400, 300
+    lo, ce, al, re = mods["synth"].generate_coo(L, N, 0.2, seed=12)
+    a_path, r_path = mods["synth"].write_mtx_pair(str(tmp_path), L, N, lo, ce, al, re)
+    g1, g2 = mods["Cellector"](0), mods["Cellector"](0)
+    for g in (g1, g2):
+        g.set_shard(100, 250)
+    g1.ingest_mtx(a_path, r_path)
+    g2.ingest_coo(L, N, lo, ce, al, re)
+    p1, p2 = g1.exchange_buffer(mods["ffi"].XCHG_PASS1), g2.exchange_buffer(mods["ffi"].XCHG_PASS1)
+    hip = _hip()
+    b1, b2 = np.empty(p1[1]), np.empty(p2[1])
+    assert hip.hipMemcpy(b1.ctypes.data, p1[0], p1[1] * 8, 2) == 0 and hip.hipMemcpy(b2.ctypes.data, p2[0], p2[1] * 8, 2) == 0
+    assert np.array_equal(b1, b2) and b1.sum() > 0
+    for g in (g1, g2):
+        g.ingest_finish(0, 0)
+    assert g1.dims().nnz_used == g2.dims().nnz_used
+    assert np.array_equal(g1.csr_rows(0, 150)[1], g2.csr_rows(0, 150)[1])
+    g1.close(); g2.close()
