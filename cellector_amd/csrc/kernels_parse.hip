@@ -16,6 +16,8 @@
 #include <unistd.h>
 #include <zlib.h>
 
+#include <thread>
+
 #include "ctx.h"
 #include "device_math.h"
 
@@ -303,8 +305,14 @@ cellector_status mtx_input_open(const cellector_ctx *c, const char *alt_path, co
     if (!in) return ctx_fail(c, CELLECTOR_ENOMEM, "out of host memory");
     cellector_status st = CELLECTOR_OK;
     std::string third;
-    if (!load_bytes(alt_path, &in->fa)) st = ctx_fail(c, CELLECTOR_EIO, "couldn't open file %s", alt_path);
-    else if (!load_bytes(ref_path, &in->fr)) st = ctx_fail(c, CELLECTOR_EIO, "couldn't open file %s", ref_path);
+    bool ok_a = false, ok_r = false;
+    {   // the two files are independent byte streams: inflate / map them concurrently
+        std::thread ta([&] { ok_a = load_bytes(alt_path, &in->fa); });
+        ok_r = load_bytes(ref_path, &in->fr);
+        ta.join();
+    }
+    if (!ok_a) st = ctx_fail(c, CELLECTOR_EIO, "couldn't open file %s", alt_path);
+    else if (!ok_r) st = ctx_fail(c, CELLECTOR_EIO, "couldn't open file %s", ref_path);
     else {
         in->off_a = skip_header(in->fa, nullptr);
         in->off_r = skip_header(in->fr, &third);

@@ -24,9 +24,7 @@
 #define T_BL 384        // loci per chunk: T_W * T_BL * 8 = 54 KB of LDS
 #define T_BC 1024       // cells per block == threads per workgroup: one lane per cell
 #define T_THREADS 1024
-#ifndef T_SB
-#define T_SB 4          // cell blocks per workgroup (they share one staged table)
-#endif
+#define T_SB_MAX 4      // cell blocks per workgroup sharing one staged table (1, 2 or 4: chosen per launch)
 #define T_CAP 6144      // entries of one tile staged per window (12 KB)
 #define T_GROUPS 8
 #define T_HDR 1088      // tile header in u16 units: 16 x {u32 wave base, u32 wave total} then 1024 x u16 offsets
@@ -76,7 +74,7 @@ __global__ void k_build_tables(uint64_t L, uint32_t nj, const double2 *__restric
 // ---------------------------------------------------------------------------------------------------------
 // cell pass over the tiles
 // ---------------------------------------------------------------------------------------------------------
-template <bool EXPECTED>
+template <bool EXPECTED, int T_SB>
 __global__ __launch_bounds__(T_THREADS, 8) void k_tile_ll(uint32_t nb, uint32_t nj, uint32_t cpg,
                                                           const uint64_t *__restrict__ tile_ptr,
                                                           const uint16_t *__restrict__ tiles,
@@ -834,14 +832,20 @@ static cellector_status run_tile_pass(cellector_ctx *c, const double2 *ab, int s
     }
     hipLaunchKernelGGL(k_build_tables, dim3(gcap((uint64_t)c->t_nj * T_BL, 256)), dim3(256), 0, c->stream, c->L, c->t_nj,
                        ab, c->lf, tab, expected ? 1 : 0);
-    const dim3 grid((c->t_nb + T_SB - 1) / T_SB, c->t_groups);
+    // several cell blocks per workgroup amortise the table staging; with few blocks (small shard) prefer more workgroups
+    int sb = T_SB_MAX;
+    while (sb > 1 && (uint64_t)((c->t_nb + sb - 1) / sb) * c->t_groups < 768) sb >>= 1;
+    const dim3 grid((c->t_nb + sb - 1) / sb, c->t_groups);
     timer_begin(c, CELLECTOR_K_TILE_LL);
-    if (expected)
-        hipLaunchKernelGGL(k_tile_ll<true>, grid, dim3(T_THREADS), 0, c->stream, c->t_nb, c->t_nj, c->t_cpg, c->tile_ptr,
-                           c->tiles, tab, c->t_npad, part_ll, part_ell);
-    else
-        hipLaunchKernelGGL(k_tile_ll<false>, grid, dim3(T_THREADS), 0, c->stream, c->t_nb, c->t_nj, c->t_cpg, c->tile_ptr,
-                           c->tiles, tab, c->t_npad, part_ll, part_ell);
+#define LAUNCH_TILE(E, S)                                                                                              \
+    hipLaunchKernelGGL((k_tile_ll<E, S>), grid, dim3(T_THREADS), 0, c->stream, c->t_nb, c->t_nj, c->t_cpg, c->tile_ptr, \
+                       c->tiles, tab, c->t_npad, part_ll, part_ell)
+    if (expected) {
+        if (sb == 4) LAUNCH_TILE(true, 4); else if (sb == 2) LAUNCH_TILE(true, 2); else LAUNCH_TILE(true, 1);
+    } else {
+        if (sb == 4) LAUNCH_TILE(false, 4); else if (sb == 2) LAUNCH_TILE(false, 2); else LAUNCH_TILE(false, 1);
+    }
+#undef LAUNCH_TILE
     timer_end(c, CELLECTOR_K_TILE_LL);
     HIPCHK(c, hipGetLastError());
     return CELLECTOR_OK;
