@@ -142,7 +142,10 @@ cellector_status cellector_set_option(cellector_ctx *c, const char *key, int64_t
     if (!strcmp(key, "compute_expected")) c->compute_expected = v != 0;
     else if (!strcmp(key, "timing")) c->timing = v != 0;
     else if (!strcmp(key, "keep_coo")) c->keep_coo = v != 0;
-    else if (!strcmp(key, "engine")) {
+    else if (!strcmp(key, "compact_bits")) {
+        if (v != 0 && v != 32) return ctx_fail(c, CELLECTOR_EINVAL, "compact_bits must be 0 (automatic) or 32");
+        c->c4_bits_opt = (int)v;
+    } else if (!strcmp(key, "engine")) {
         if (v != 1 && v != 2) return ctx_fail(c, CELLECTOR_EINVAL, "engine must be 1 (CSR/CSC kernels) or 2 (tiled)");
         if (c->em_phase != 0) return ctx_fail(c, CELLECTOR_EINVAL, "cannot switch engine inside an iteration");
         if (v == 2 && c->state == cellector_ctx::ST_READY && !c->tiled_ready) {

@@ -95,7 +95,9 @@ struct cellector_ctx {
     double *ovf_tab = nullptr;       // [L][64] per-locus cumulative-log / expected tables for overflow entries
     double2 *ovf_val = nullptr;      // [3][ovf_n] (log-pmf, expected term) of overflow entries, by-locus order
     uint64_t *c4_ptr = nullptr;      // [L+1] compact CSC of regular entries
-    uint32_t *c4_ent = nullptr;      // cell_local | code << 28
+    uint32_t *c4_ent = nullptr;      // 32-bit entries cell_local | code << 28, or 24-bit cell | code << 20 (c4_bits)
+    int c4_bits = 32;
+    int c4_bits_opt = 0;             // option "compact_bits": 0 = automatic, 32 = force the 32-bit entries
     uint64_t *ovc_ptr = nullptr, *ovc_ent = nullptr;    // overflow CSC, packed like csc_ent
     uint32_t *hist_all = nullptr;    // [L][9] regular entries per code
     double *tab = nullptr;           // [3][nj][12][512] log-pmf / expected tables (set 0: EM pass; 0..2: posterior)

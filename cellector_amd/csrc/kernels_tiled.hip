@@ -201,28 +201,40 @@ __device__ __noinline__ double ov_slow_expected(const double *lf, double alpha, 
     return dm_expected_log_pmf(lf, alpha, beta, n);
 }
 
-// Per-locus overflow table, 64 doubles: [0..17] LA[i] = sum_{m<i} ln(alpha+m), [18..35] LB, [36..53] LAB,
-// [64..77] E(n) for n = 4..17 (ln sum_k pmf(k)^2, stats.rs:8-22).  One thread per locus.
+// Per-locus overflow table (OV_ROW doubles): [0..17] LA[i] = sum_{m<i} ln(alpha+m), [18..35] LB, [36..53] LAB,
+// [64..] E(n) for n = 4..OV_NE (ln sum_k pmf(k)^2, stats.rs:8-22).  32 lanes per locus: lane i < 17 takes the three
+// logs of index i, a width-32 shuffle scan turns them into the cumulative sums.
 #define OV_ROW 128
 #define OV_EOFF 64
-__global__ void k_ovf_tables(uint64_t L, const double2 *__restrict__ ab, double *__restrict__ otab)
+__global__ __launch_bounds__(256) void k_ovf_tables(uint64_t L, const double2 *__restrict__ ab, double *__restrict__ otab)
 {
-    const uint64_t l = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (l >= L) return;
+    const uint64_t l = ((uint64_t)blockIdx.x * 256 + threadIdx.x) >> 5;
+    const int i = threadIdx.x & 31;
+    const bool in = l < L;
+    const double2 p = in ? ab[l] : make_double2(1.0, 1.0);
+    const bool live = p.x >= 0.0;
+    double ta = 0.0, tb = 0.0, tc = 0.0;
+    if (live && i < OV_NT - 1) {
+        ta = log(p.x + (double)i);
+        tb = log(p.y + (double)i);
+        tc = log((p.x + p.y) + (double)i);
+    }
+    double ia = ta, ib = tb, ic = tc;
+#pragma unroll
+    for (int off = 1; off < 32; off <<= 1) {
+        const double oa = __shfl_up(ia, off, 32), ob = __shfl_up(ib, off, 32), oc = __shfl_up(ic, off, 32);
+        if (i >= off) { ia += oa; ib += ob; ic += oc; }
+    }
+    if (!in) return;
     double *row = otab + l * OV_ROW;
-    const double2 p = ab[l];
-    if (!(p.x >= 0.0)) {
-        row[0] = -1.0;  // marks a masked locus
+    if (!live) {
+        if (i == 0) row[0] = -1.0;  // marks a masked locus
         return;
     }
-    double la = 0.0, lb = 0.0, lab = 0.0;
-    for (int i = 0; i < OV_NT; i++) {
-        row[i] = la;
-        row[OV_NT + i] = lb;
-        row[2 * OV_NT + i] = lab;
-        la += log(p.x + (double)i);
-        lb += log(p.y + (double)i);
-        lab += log((p.x + p.y) + (double)i);
+    if (i < OV_NT) {  // exclusive prefix: lane i holds the sum of the terms below i
+        row[i] = ia - ta;
+        row[OV_NT + i] = ib - tb;
+        row[2 * OV_NT + i] = ic - tc;
     }
 }
 
@@ -349,8 +361,34 @@ __global__ __launch_bounds__(256) void k_ovf_finalize(uint64_t n_rows, const uin
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// locus pass over the compact CSC
+// locus pass over the compact CSC.  Two entry widths: 24 bits (cell 20 | code 4; four entries = three dwords) when
+// the shard has at most 2^20 cells, else 32 bits (cell 28 | code 4).  The pass is a pure HBM stream, so bytes matter.
 // ---------------------------------------------------------------------------------------------------------
+template <int EB>
+__device__ __forceinline__ void c4_read1(const uint32_t *__restrict__ base, uint64_t i, uint32_t *cell, uint32_t *code)
+{
+    if (EB == 32) {
+        const uint32_t x = base[i];
+        *cell = x & 0x0fffffffu;
+        *code = x >> 28;
+    } else {
+        const uint8_t *b = reinterpret_cast<const uint8_t *>(base) + 3 * i;
+        const uint32_t v = (uint32_t)b[0] | ((uint32_t)b[1] << 8) | ((uint32_t)b[2] << 16);
+        *cell = v & 0xfffffu;
+        *code = v >> 20;
+    }
+}
+template <int EB>
+__device__ __forceinline__ void c4_write1(uint32_t *__restrict__ base, uint64_t i, uint32_t cell, uint32_t code)
+{
+    if (EB == 32) {
+        base[i] = cell | (code << 28);
+    } else {
+        uint8_t *b = reinterpret_cast<uint8_t *>(base) + 3 * i;
+        const uint32_t v = cell | (code << 20);
+        b[0] = (uint8_t)v; b[1] = (uint8_t)(v >> 8); b[2] = (uint8_t)(v >> 16);
+    }
+}
 __global__ void k_pack_flag_bits(uint64_t n, const uint8_t *__restrict__ flags, uint32_t *__restrict__ bits)
 {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -362,7 +400,7 @@ __global__ void k_pack_flag_bits(uint64_t n, const uint8_t *__restrict__ flags, 
 #define LS_THREADS 1024
 #define LS_NPK ((T_NCODE + 4) / 5)
 #define LS_FLUSH 15  // vector iterations between wave reductions: 15*4 = 60 per lane and field, 64*60 < 4096 (12-bit fields)
-template <bool BITS_IN_LDS>
+template <bool BITS_IN_LDS, int EB>
 __global__ __launch_bounds__(LS_THREADS) void k_locus_stats2(uint64_t L, uint32_t nbits_words,
                                                              const uint64_t *__restrict__ c4_ptr,
                                                              const uint32_t *__restrict__ c4_ent,
@@ -383,26 +421,37 @@ __global__ __launch_bounds__(LS_THREADS) void k_locus_stats2(uint64_t L, uint32_
     const uint64_t wave0 = (uint64_t)blockIdx.x * (LS_THREADS / 64) + (threadIdx.x >> 6);
     const uint64_t nwaves = (uint64_t)gridDim.x * (LS_THREADS / 64);
     for (uint64_t l = wave0; l < L; l += nwaves) {
-        // columns are padded to whole 16-byte vectors with 0xFFFFFFFF (code 15 = no entry)
+        // columns are padded to groups of four entries (code 15 = no entry): 16 bytes at 32 bits, 12 bytes at 24 bits
         const uint64_t vbeg = c4_ptr[l] >> 2, nvec = (c4_ptr[l + 1] >> 2) - vbeg;
-        const uint4 *vp = reinterpret_cast<const uint4 *>(c4_ent) + vbeg;
+        const uint32_t *wp = c4_ent + vbeg * (EB == 32 ? 4 : 3);
         // minority entries are few: they vote into this wave's 16-bin LDS histogram (integer atomics: exact)
         for (uint64_t i0 = 0; i0 < nvec; i0 += 4 * 64) {
-            // four independent 16-byte loads per lane in flight (4 KB per wave): the pass is a pure stream
-            uint4 v[4];
+            // four independent loads per lane in flight: the pass is a pure stream
+            uint32_t cellv[4][4], codev[4][4];
 #pragma unroll
             for (int u = 0; u < 4; u++) {
                 const uint64_t i = i0 + (uint64_t)u * 64 + lane;
-                v[u] = make_uint4(~0u, ~0u, ~0u, ~0u);
-                if (i < nvec) v[u] = vp[i];
+                if (EB == 32) {
+                    uint4 v = make_uint4(~0u, ~0u, ~0u, ~0u);
+                    if (i < nvec) v = reinterpret_cast<const uint4 *>(wp)[i];
+                    const uint32_t xs[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int q = 0; q < 4; q++) { cellv[u][q] = xs[q] & 0x0fffffffu; codev[u][q] = xs[q] >> 28; }
+                } else {
+                    uint32_t w0 = ~0u, w1 = ~0u, w2 = ~0u;
+                    if (i < nvec) { w0 = wp[3 * i]; w1 = wp[3 * i + 1]; w2 = wp[3 * i + 2]; }
+                    const uint32_t es[4] = {w0 & 0xffffffu, (w0 >> 24) | ((w1 & 0xffffu) << 8), (w1 >> 16) | ((w2 & 0xffu) << 16),
+                                            w2 >> 8};
+#pragma unroll
+                    for (int q = 0; q < 4; q++) { cellv[u][q] = es[q] & 0xfffffu; codev[u][q] = es[q] >> 20; }
+                }
             }
 #pragma unroll
             for (int u = 0; u < 4; u++) {
-                const uint32_t xs[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
-                    const uint32_t x = xs[q], code = x >> 28;
-                    const uint32_t cell = code < (uint32_t)T_NCODE ? (x & 0x0fffffffu) : 0u;
+                    const uint32_t code = codev[u][q];
+                    const uint32_t cell = code < (uint32_t)T_NCODE ? cellv[u][q] : 0u;
                     if (code < (uint32_t)T_NCODE && ((bits[cell >> 5] >> (cell & 31)) & 1u)) atomicAdd(&whist[code], 1u);
                 }
             }
@@ -480,6 +529,7 @@ __global__ __launch_bounds__(256) void k_locus_ovf(uint64_t L, const uint64_t *_
 }
 
 // entries of newly masked loci no longer count as used loci of their cells (main.rs:556,575)
+template <int EB>
 __global__ __launch_bounds__(256) void k_masked_update(uint64_t L, const uint8_t *__restrict__ mask_old,
                                                        const uint8_t *__restrict__ mask_new,
                                                        const uint64_t *__restrict__ c4_ptr,
@@ -493,8 +543,9 @@ __global__ __launch_bounds__(256) void k_masked_update(uint64_t L, const uint8_t
     for (uint64_t l = wave0; l < L; l += nwaves) {
         if (!(mask_old[l] && !mask_new[l])) continue;
         for (uint64_t i = c4_ptr[l] + lane; i < c4_ptr[l + 1]; i += 64) {
-            const uint32_t x = c4_ent[i];
-            if ((x >> 28) < (uint32_t)T_NCODE) atomicAdd(&masked_cnt[x & 0x0fffffffu], 1u);
+            uint32_t cell, code;
+            c4_read1<EB>(c4_ent, i, &cell, &code);
+            if (code < (uint32_t)T_NCODE) atomicAdd(&masked_cnt[cell], 1u);
         }
         for (uint64_t i = ovc_ptr[l] + lane; i < ovc_ptr[l + 1]; i += 64) atomicAdd(&masked_cnt[ENT_IDX(ovc_ent[i])], 1u);
     }
@@ -653,7 +704,7 @@ __global__ __launch_bounds__(256) void k_ovf_build(uint64_t n_rows, const uint64
 }
 
 // wave per locus column: regular entries -> compact u32 (cell | code<<28) in order; per-code histogram
-template <bool FILL>
+template <bool FILL, int EB>
 __global__ __launch_bounds__(256) void k_c4_build(uint64_t L, const uint64_t *__restrict__ csc_ptr,
                                                   const uint64_t *__restrict__ csc_ent, uint64_t *__restrict__ c4_ptr,
                                                   uint32_t *__restrict__ c4_ent, uint32_t *__restrict__ hist_all)
@@ -671,7 +722,7 @@ __global__ __launch_bounds__(256) void k_c4_build(uint64_t L, const uint64_t *__
             const uint32_t code = reg ? ent_code(e) : 0xffu;
             const unsigned long long m = __ballot(reg);
             if (FILL) {
-                if (reg) c4_ent[base + __popcll(m & ((1ull << lane) - 1ull))] = ENT_IDX(e) | (code << 28);
+                if (reg) c4_write1<EB>(c4_ent, base + __popcll(m & ((1ull << lane) - 1ull)), ENT_IDX(e), code);
             } else {
 #pragma unroll
                 for (int k = 0; k < T_NCODE; k++) {
@@ -686,7 +737,7 @@ __global__ __launch_bounds__(256) void k_c4_build(uint64_t L, const uint64_t *__
             if (lane == 0) c4_ptr[l] = (cnt + 3) & ~3ull;  // whole 16-byte vectors
             if (lane < T_NCODE) hist_all[l * T_NCODE + lane] = myhist;
         } else if ((uint64_t)lane < ((4 - (cnt & 3)) & 3)) {
-            c4_ent[c4_ptr[l] + cnt + lane] = 0xffffffffu;      // padding: code 15 = no entry
+            c4_write1<EB>(c4_ent, c4_ptr[l] + cnt + lane, EB == 32 ? 0x0fffffffu : 0xfffffu, 15u);  // padding: code 15 = no entry
         }
     }
 }
@@ -765,7 +816,7 @@ cellector_status tiled_build(cellector_ctx *c)
     HIPCHK(c, hipMemsetAsync(c->c4_ptr + L, 0, 8, c->stream));
     HIPCHK(c, hipMemsetAsync(c->ovc_ptr + L, 0, 8, c->stream));
     if (L) {
-        hipLaunchKernelGGL(k_c4_build<false>, dim3(gcap(L, 4)), dim3(256), 0, c->stream, L, c->csc_ptr, c->csc_ent,
+        hipLaunchKernelGGL((k_c4_build<false, 32>), dim3(gcap(L, 4)), dim3(256), 0, c->stream, L, c->csc_ptr, c->csc_ent,
                            c->c4_ptr, (uint32_t *)nullptr, c->hist_all);
         hipLaunchKernelGGL(k_ovf_build<false>, dim3(gcap(L, 4)), dim3(256), 0, c->stream, L, c->csc_ptr, c->csc_ent,
                            c->ovc_ptr, (uint64_t *)nullptr);
@@ -777,11 +828,16 @@ cellector_status tiled_build(cellector_ctx *c)
         return ctx_fail(c, CELLECTOR_EDEVICE, "internal: tiled build entry counts inconsistent (%llu + %llu vs %llu, ovf %llu)",
                         (unsigned long long)n4, (unsigned long long)novc, (unsigned long long)c->nnz,
                         (unsigned long long)c->ovf_n);
-    CHK(dev_alloc(c, &c->c4_ent, n4));
+    c->c4_bits = (nloc <= (1ull << 20) && c->c4_bits_opt != 32) ? 24 : 32;
+    CHK(dev_alloc(c, &c->c4_ent, c->c4_bits == 32 ? n4 : (n4 * 3 + 3) / 4 + 4));
     CHK(dev_alloc(c, &c->ovc_ent, novc));
     if (L) {
-        hipLaunchKernelGGL(k_c4_build<true>, dim3(gcap(L, 4)), dim3(256), 0, c->stream, L, c->csc_ptr, c->csc_ent,
-                           c->c4_ptr, c->c4_ent, c->hist_all);
+        if (c->c4_bits == 32)
+            hipLaunchKernelGGL((k_c4_build<true, 32>), dim3(gcap(L, 4)), dim3(256), 0, c->stream, L, c->csc_ptr, c->csc_ent,
+                               c->c4_ptr, c->c4_ent, c->hist_all);
+        else
+            hipLaunchKernelGGL((k_c4_build<true, 24>), dim3(gcap(L, 4)), dim3(256), 0, c->stream, L, c->csc_ptr, c->csc_ent,
+                               c->c4_ptr, c->c4_ent, c->hist_all);
         hipLaunchKernelGGL(k_ovf_build<true>, dim3(gcap(L, 4)), dim3(256), 0, c->stream, L, c->csc_ptr, c->csc_ent,
                            c->ovc_ptr, c->ovc_ent);
     }
@@ -819,7 +875,7 @@ static cellector_status run_tile_pass(cellector_ctx *c, const double2 *ab, int s
     double *part_ell = part_ll + (uint64_t)c->t_groups * c->t_npad;
     if (c->ovf_n && c->L) {
         double2 *val = c->ovf_val + (uint64_t)set * c->ovf_n;
-        hipLaunchKernelGGL(k_ovf_tables, dim3(gcap(c->L, 256)), dim3(256), 0, c->stream, c->L, ab, c->ovf_tab);
+        hipLaunchKernelGGL(k_ovf_tables, dim3(gcap(c->L * 32, 256, 0x7fffffffu)), dim3(256), 0, c->stream, c->L, ab, c->ovf_tab);
         if (expected)
             hipLaunchKernelGGL(k_ovf_tables_e, dim3(gcap(c->L * (OV_NE - 3), 256, 0x7fffffffu)), dim3(256), 0, c->stream, c->L,
                                c->lf, c->ovf_tab);
@@ -885,15 +941,22 @@ cellector_status tiled_locus_pass(cellector_ctx *c)
     unsigned grid = (unsigned)ncu;
     const uint64_t need = (c->L + LS_THREADS / 64 - 1) / (LS_THREADS / 64);
     if (grid > need) grid = (unsigned)(need ? need : 1);
+#define LAUNCH_LS(INLDS, EBV, GRID, LDSB)                                                                              \
+    hipLaunchKernelGGL((k_locus_stats2<INLDS, EBV>), dim3(GRID), dim3(LS_THREADS), LDSB, c->stream, c->L, words, c->c4_ptr, \
+                       c->c4_ent, c->flag_bits, c->hist_all, c->tab, c->mask, c->x_locus)
     if (lds <= 128 * 1024) {
-        HIPCHK(c, hipFuncSetAttribute((const void *)k_locus_stats2<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      (int)(lds ? lds : 4)));
-        hipLaunchKernelGGL(k_locus_stats2<true>, dim3(grid), dim3(LS_THREADS), lds ? lds : 4, c->stream, c->L, words,
-                           c->c4_ptr, c->c4_ent, c->flag_bits, c->hist_all, c->tab, c->mask, c->x_locus);
+        const int lb = (int)(lds ? lds : 4);
+        if (c->c4_bits == 24) {
+            HIPCHK(c, hipFuncSetAttribute((const void *)k_locus_stats2<true, 24>, hipFuncAttributeMaxDynamicSharedMemorySize, lb));
+            LAUNCH_LS(true, 24, grid, lb);
+        } else {
+            HIPCHK(c, hipFuncSetAttribute((const void *)k_locus_stats2<true, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, lb));
+            LAUNCH_LS(true, 32, grid, lb);
+        }
     } else {
-        hipLaunchKernelGGL(k_locus_stats2<false>, dim3(grid * 2), dim3(LS_THREADS), 4, c->stream, c->L, words, c->c4_ptr,
-                           c->c4_ent, c->flag_bits, c->hist_all, c->tab, c->mask, c->x_locus);
+        LAUNCH_LS(false, 32, grid * 2, 4);  // more than 2^20 cells per shard: 32-bit entries, bitmask read from L2
     }
+#undef LAUNCH_LS
     if (c->ovf_n)
         hipLaunchKernelGGL(k_locus_ovf, dim3(gcap(c->L, 4)), dim3(256), 0, c->stream, c->L, c->ovc_ptr, c->ovc_ent,
                            c->ovf_val, c->mask, c->flags_new, c->x_locus);
@@ -906,8 +969,12 @@ cellector_status tiled_locus_pass(cellector_ctx *c)
 cellector_status tiled_masked_update(cellector_ctx *c)
 {
     if (c->L == 0) return CELLECTOR_OK;
-    hipLaunchKernelGGL(k_masked_update, dim3(gcap(c->L, 4)), dim3(256), 0, c->stream, c->L, c->mask, c->mask_next, c->c4_ptr,
-                       c->c4_ent, c->ovc_ptr, c->ovc_ent, c->masked_cnt);
+    if (c->c4_bits == 24)
+        hipLaunchKernelGGL(k_masked_update<24>, dim3(gcap(c->L, 4)), dim3(256), 0, c->stream, c->L, c->mask, c->mask_next,
+                           c->c4_ptr, c->c4_ent, c->ovc_ptr, c->ovc_ent, c->masked_cnt);
+    else
+        hipLaunchKernelGGL(k_masked_update<32>, dim3(gcap(c->L, 4)), dim3(256), 0, c->stream, c->L, c->mask, c->mask_next,
+                           c->c4_ptr, c->c4_ent, c->ovc_ptr, c->ovc_ent, c->masked_cnt);
     HIPCHK(c, hipGetLastError());
     return CELLECTOR_OK;
 }

@@ -53,7 +53,9 @@ cellector_status cellector_set_stream(cellector_ctx *ctx, void *hip_stream);
  * "timing" (default 0: record HIP events around the dominant kernels),
  * "keep_coo" (default 1: keep the staged all-loci COO for cellector_final_allele_tallies),
  * "engine" (default 2: table-driven passes over the tiled 16-bit layout; 1: CSR/CSC kernels that
- * evaluate every entry's log-pmf — same results within rounding, kept for A/B checks). */
+ * evaluate every entry's log-pmf — same results within rounding, kept for A/B checks),
+ * "compact_bits" (default 0: the locus pass stores 24-bit entries when the shard has <= 2^20 cells,
+ * else 32-bit; 32 forces the wide form — set before ingest). */
 cellector_status cellector_set_option(cellector_ctx *ctx, const char *key, int64_t value);
 
 /* ---- sharding (before ingest) --------------------------------------------------------------- */

@@ -136,6 +136,18 @@ def test_doublets_and_small_minority(mods):
     g.close()
 
 
+def test_wide_compact_entries(mods):
+    """The locus pass stores 24-bit entries for shards of up to 2^20 cells; force the 32-bit form used beyond that."""
+    lo, ce, al, re = mods["synth"].generate_coo(1200, 900, 0.1, seed=21, minority_fraction=0.09)
+    g = mods["Cellector"](0)
+    g.set_option("compact_bits", 32)
+    g.load_coo(1200, 900, lo, ce, al, re)
+    o = mods["ob"].Oracle.from_coo(1200, 900, lo, ce, al, re)
+    _run_both(g, o)
+    _check_posteriors(mods, g, o)
+    g.close()
+
+
 def test_ll_pass_under_caller_alpha_beta_and_mask(mods):
     g, o, _ = _case(mods, 1500, 800, 0.1, seed=3)
     rng = np.random.default_rng(0)
