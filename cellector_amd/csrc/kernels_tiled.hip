@@ -25,7 +25,7 @@
 #define T_BC 1024       // cells per block == threads per workgroup: one lane per cell
 #define T_THREADS 1024
 #define T_SB_MAX 4      // cell blocks per workgroup sharing one staged table (1, 2 or 4: chosen per launch)
-#define T_CAP 6144      // entries of one tile staged per window (12 KB)
+#define T_CAP 4096      // entries of one tile staged per window: 4 per lane (8 KB)
 #define T_GROUPS 8
 #define T_HDR 1088      // tile header in u16 units: 16 x {u32 wave base, u32 wave total} then 1024 x u16 offsets
                         // (exclusive, relative to the base of the cell's wave: < 64 * T_BL)
@@ -74,6 +74,11 @@ __global__ void k_build_tables(uint64_t L, uint32_t nj, const double2 *__restric
 // ---------------------------------------------------------------------------------------------------------
 // cell pass over the tiles
 // ---------------------------------------------------------------------------------------------------------
+// Workgroup barrier that waits for this wave's LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it would wait
+// for the prefetch loads issued just before it and make them synchronous; here they stay in flight across the barrier
+// and the compiler's own s_waitcnt guards their first use one step later.
+#define TILE_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
 template <bool EXPECTED, int T_SB>
 __global__ __launch_bounds__(T_THREADS, 8) void k_tile_ll(uint32_t nb, uint32_t nj, uint32_t cpg,
                                                           const uint64_t *__restrict__ tile_ptr,
@@ -84,51 +89,50 @@ __global__ __launch_bounds__(T_THREADS, 8) void k_tile_ll(uint32_t nb, uint32_t 
     // A workgroup owns T_SB consecutive 1024-cell blocks (one lane per cell of each) and one group of locus chunks.
     // Per chunk the table (54 KB) is staged ONCE and the T_SB tiles are consumed one after the other through a
     // double-buffered entry window; what is needed next (the next tile's window + header words, the next chunk's
-    // table) travels in registers while the current tile is consumed.  Ablations on cfg4 (profiles/): the
-    // table re-staging traffic from L2 / Infinity Cache and the barrier skeleton weigh as much as the lookups, hence
-    // several cell blocks per staged table and nothing consumed in the step that loaded it.
+    // table) travels in registers while the current tile is consumed.
+    //
+    // Load discipline (vmcnt counts in issue order and the compiler waits conservatively around branches): in every
+    // step the values loaded one step earlier are consumed FIRST, then the next loads are issued as straight-line,
+    // unconditional instructions (indices are clamped instead of guarded), and the workgroup barrier waits for LDS
+    // traffic only.  So nothing is ever waited for in the step that issued it.
     __shared__ double s_tab[T_W * T_BL];
-    __shared__ uint4 s_ent[2][T_CAP / 8];
+    __shared__ uint2 s_ent[2][T_CAP / 4];
     const uint32_t tid = threadIdx.x;
     const uint32_t b0 = blockIdx.x * T_SB, g = blockIdx.y;
     const uint32_t j0 = g * cpg, j1 = min(nj, j0 + cpg);
     double ll[T_SB], el[T_SB];
 #pragma unroll
     for (int s = 0; s < T_SB; s++) ll[s] = el[s] = 0.0;
+    if (j0 >= j1) return;
 
-    static_assert(T_NP == 4, "table prefetch registers are written out by hand");
-    double2 p_tab0, p_tab1, p_tab2, p_tab3 = make_double2(0.0, 0.0);
-    uint32_t p_rel = 0, p_tot = 0;
-    uint2 p_wb = make_uint2(0, 0);
-    uint4 p_ent = make_uint4(0, 0, 0, 0);
+    static_assert(T_NP == 4 && T_CAP / 4 == T_THREADS, "prefetch registers are written out by hand");
+    double2 p_tab0, p_tab1, p_tab2, p_tab3;
+    uint32_t p_rel, p_tot;
+    uint2 p_wb, p_ent;
+    // the fourth table load of a thread may run past the chunk (into the next chunk / the tail pad): never stored
 #define TABLE_PREFETCH(J)                                                                                       \
     do {                                                                                                        \
         const double2 *src__ = reinterpret_cast<const double2 *>(tab + (uint64_t)(J) * (T_W * T_BL));           \
         p_tab0 = src__[tid];                                                                                    \
         p_tab1 = src__[tid + T_THREADS];                                                                        \
         p_tab2 = src__[tid + 2 * T_THREADS];                                                                    \
-        if (tid + 3 * T_THREADS < T_W * T_BL / 2) p_tab3 = src__[tid + 3 * T_THREADS];                          \
+        p_tab3 = src__[tid + 3 * T_THREADS];                                                                    \
     } while (0)
+    // block index clamped: a workgroup at the ragged end re-reads the last block and discards the result
 #define TILE_PREFETCH(J, S)                                                                                     \
     do {                                                                                                        \
-        p_tot = 0; p_rel = 0; p_wb = make_uint2(0, 0);                                                          \
-        if (b0 + (S) < nb) {                                                                                    \
-            const uint64_t t__ = (uint64_t)(b0 + (S)) * nj + (J);                                               \
-            const uint64_t o__ = tile_ptr[t__];                                                                 \
-            p_tot = (uint32_t)(tile_ptr[t__ + 1] - o__) - T_HDR; /* entries, padded to a multiple of 8 */       \
-            p_wb = reinterpret_cast<const uint2 *>(tiles + o__)[tid >> 6]; /* wave base, wave total */          \
-            p_rel = (tiles + o__ + 64)[tid];            /* consumed one step later: the loads stay in flight */ \
-            if (tid < min(p_tot, (uint32_t)T_CAP) / 8)                                                          \
-                p_ent = reinterpret_cast<const uint4 *>(tiles + o__ + T_HDR)[tid];                              \
-        }                                                                                                       \
+        const uint64_t t__ = (uint64_t)min(b0 + (uint32_t)(S), nb - 1) * nj + (J);                              \
+        const uint64_t o__ = tile_ptr[t__];                                                                     \
+        p_tot = (uint32_t)(tile_ptr[t__ + 1] - o__) - T_HDR; /* entries, padded to a multiple of 8 */           \
+        p_wb = reinterpret_cast<const uint2 *>(tiles + o__)[tid >> 6]; /* wave base, wave total */              \
+        p_rel = (tiles + o__ + 64)[tid];                                                                        \
+        p_ent = reinterpret_cast<const uint2 *>(tiles + o__ + T_HDR)[tid]; /* first window: 4 entries a lane */ \
     } while (0)
 
-    if (j0 < j1) {
-        TABLE_PREFETCH(j0);
-        TILE_PREFETCH(j0, 0);
-    }
+    TABLE_PREFETCH(j0);
+    TILE_PREFETCH(j0, 0);
     for (uint32_t j = j0; j < j1; j++) {
-        __syncthreads();  // every wave is done with the previous chunk's table
+        TILE_BARRIER();  // every wave is done with the previous chunk's table
         {
             double2 *dst = reinterpret_cast<double2 *>(s_tab);
             dst[tid] = p_tab0;
@@ -136,27 +140,30 @@ __global__ __launch_bounds__(T_THREADS, 8) void k_tile_ll(uint32_t nb, uint32_t 
             dst[tid + 2 * T_THREADS] = p_tab2;
             if (tid + 3 * T_THREADS < T_W * T_BL / 2) dst[tid + 3 * T_THREADS] = p_tab3;
         }
-        if (j + 1 < j1) TABLE_PREFETCH(j + 1);
+        const uint32_t jn = min(j + 1, j1 - 1);
 #pragma unroll
         for (int s = 0; s < T_SB; s++) {
-            uint4 *win = s_ent[s & 1];
+            uint2 *win = s_ent[s & 1];
+            // 1. consume what was loaded one step ago
             uint32_t nxt = (uint32_t)__shfl_down((int)p_rel, 1, 64);  // the next cell's offset = this cell's end
             if ((tid & 63) == 63) nxt = p_wb.y;
             const uint32_t my_s = p_wb.x + p_rel, my_e = p_wb.x + nxt, total = p_tot;
-            if (tid < min(total, (uint32_t)T_CAP) / 8) win[tid] = p_ent;
-            // the next tile's loads go out BEFORE the barrier: the barrier wait is latency-hiding time too
+            win[tid] = p_ent;
+            // 2. issue the next step's loads
+            if (s == 0) TABLE_PREFETCH(jn);
             if (s + 1 < T_SB) TILE_PREFETCH(j, s + 1);
-            else if (j + 1 < j1) TILE_PREFETCH(j + 1, 0);
-            __syncthreads();  // window s (and, for s == 0, the table) visible; window s-2 no longer read by anybody
+            else TILE_PREFETCH(jn, 0);
+            TILE_BARRIER();  // window s (and, for s == 0, the table) visible; window s-2 no longer read by anybody
+            // 3. walk this lane's segment
             const uint16_t *se = reinterpret_cast<const uint16_t *>(win);
             double a_ll = ll[s], a_el = el[s];
             for (uint32_t w0 = 0; w0 < total; w0 += T_CAP) {  // total is uniform over the workgroup
                 const uint32_t n_in = min((uint32_t)T_CAP, total - w0);
                 if (w0) {  // a tile larger than one window (dense data): stage the next window synchronously
-                    const uint16_t *tp = tiles + tile_ptr[(uint64_t)(b0 + s) * nj + j];
-                    const uint4 *ep = reinterpret_cast<const uint4 *>(tp + T_HDR);
+                    const uint16_t *tp = tiles + tile_ptr[(uint64_t)min(b0 + (uint32_t)s, nb - 1) * nj + j];
+                    const uint2 *ep = reinterpret_cast<const uint2 *>(tp + T_HDR);
                     __syncthreads();
-                    for (uint32_t i = tid; i < (n_in >> 3); i += T_THREADS) win[i] = ep[(w0 >> 3) + i];
+                    win[tid] = ep[(w0 >> 2) + tid];
                     __syncthreads();
                 }
                 const uint32_t klo = max(my_s, w0), khi = min(my_e, w0 + n_in);
@@ -787,7 +794,7 @@ cellector_status tiled_build(cellector_ctx *c)
     HIPCHK(c, hipGetLastError());
     uint64_t elems = 0;
     CHK(dev_exclusive_scan_u64(c, c->tile_ptr, nt + 1, &elems));
-    CHK(dev_alloc(c, &c->tiles, elems + T_CAP + 8));  // tail pad: the window prefetch may read past the last tile
+    CHK(dev_alloc(c, &c->tiles, elems + 2 * T_CAP + 8));  // tail pad: window loads may read past the last tile
     for (uint64_t t0 = 0; t0 < nt; t0 += maxg) {
         const uint64_t g = nt - t0 < maxg ? nt - t0 : maxg;
         hipLaunchKernelGGL(k_tile_build<true>, dim3((unsigned)g), dim3(T_BC), 0, c->stream, nloc, c->t_nj, t0, c->csr_ptr,
@@ -855,7 +862,7 @@ cellector_status tiled_build(cellector_ctx *c)
 
     // ---- per-iteration workspaces
     const uint64_t tab_elems = (uint64_t)c->t_nj * T_W * T_BL;
-    CHK(dev_alloc(c, &c->tab, 3 * tab_elems));
+    CHK(dev_alloc(c, &c->tab, 3 * tab_elems + 2 * T_THREADS));  // tail pad for the unconditional fourth table load
     CHK(dev_alloc(c, &c->part, 3ull * 2 * c->t_groups * c->t_npad));
     CHK(dev_alloc(c, &c->ab3, 3 * L));
     CHK(dev_alloc(c, &c->masked_cnt, nloc));
