@@ -63,12 +63,27 @@ def lib():
         "orc_assignments": (None, [vp, vp, vp, d, u64, vp, vp, vp]),
         "orc_final_tallies_coo": (None, [u64, u64] + [vp] * 9),
         "orc_vcf_genotype": (None, [u64, u64, u64, u64, vp, vp, vp, vp]),
+        "orc_set_threads": (None, [C.c_int]), "orc_get_threads": (C.c_int, []),
     }
     for name, (res, args) in sig.items():
         f = getattr(L, name)
         f.restype, f.argtypes = res, args
     _lib = L
     return L
+
+
+def set_threads(n):
+    """Worker threads of the oracle's per-cell loop (default 1, like the single-threaded reference).  Results are
+    bit-identical for any count; the large parity tests use the host's cores so that they finish in seconds."""
+    lib().orc_set_threads(int(n))
+
+
+def host_threads(cap=32):
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(cap, n))
 
 
 def _p(a):

@@ -516,15 +516,35 @@ static void pmfs_reserve(orc_ctx *c, uint64_t n)
     c->cap_pmfs = n;
 }
 
+/* Worker threads for the per-cell loop below.  Default 1: the reference is single-threaded and the
+ * cpu_baseline leg times one core.  Cells are independent and each cell's sums stay sequential in file
+ * order, so any thread count gives bit-identical results; the large parity tests use all host cores. */
+static int g_threads = 1;
+void orc_set_threads(int n) { g_threads = n > 0 ? n : 1; }
+int orc_get_threads(void) { return g_threads; }
+
 /* get_cell_log_likelihoods — main.rs:541-591 */
 static void get_cell_log_likelihoods(orc_ctx *c, const uint8_t *loci_used, const double *alpha,
                                      const double *beta, const uint8_t *excluded, double *ll,
                                      double *ell, double *evar, double *nloci)
 {
     pmfs_reserve(c, c->nnz);
-    uint64_t np = 0;
-    for (uint64_t cell = 0; cell < c->total_cells; cell++) {
+    lbc_init(); /* static tables are built before the loop (no lazy init inside worker threads) */
+    const uint64_t N = c->total_cells;
+    /* position of each cell's first PMFData in all_pmfs (the reference pushes them in cell order) */
+    uint64_t *first = (uint64_t *)xcalloc(N + 1, 8);
+    for (uint64_t cell = 0; cell < N; cell++) {
+        uint64_t used = 0;
+        for (uint64_t i = c->row_ptr[cell]; i < c->row_ptr[cell + 1]; i++)
+            used += loci_used[c->entries[i].locus_index] ? 1 : 0;
+        first[cell + 1] = first[cell] + used;
+    }
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 64) num_threads(g_threads) if (g_threads > 1)
+#endif
+    for (uint64_t cell = 0; cell < N; cell++) {
         double log_likelihood = 0.0, expected_ll = 0.0, expected_var = 0.0, used = 0.0;
+        uint64_t np = first[cell];
         for (uint64_t i = c->row_ptr[cell]; i < c->row_ptr[cell + 1]; i++) {
             const cell_locus *e = &c->entries[i];
             if (!loci_used[e->locus_index]) continue;
@@ -547,7 +567,8 @@ static void get_cell_log_likelihoods(orc_ctx *c, const uint8_t *loci_used, const
         if (ell) ell[cell] = expected_ll;
         if (evar) evar[cell] = expected_var;
     }
-    c->n_pmfs = np;
+    c->n_pmfs = first[N];
+    free(first);
 }
 
 void orc_cell_log_likelihoods(orc_ctx *c, const double *alpha, const double *beta,

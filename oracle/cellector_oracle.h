@@ -96,6 +96,10 @@ void orc_iter_locus_outputs(const orc_ctx *, double *contrib_min, double *contri
 void orc_loci_mask(const orc_ctx *, uint8_t *out /*[L]*/);
 void orc_excluded(const orc_ctx *, uint8_t *out /*[N]*/);
 void orc_set_excluded(orc_ctx *, const uint8_t *in /*[N]*/);
+/* worker threads of the per-cell loop (default 1 = like the single-threaded reference; results are
+ * bit-identical for any count) */
+void orc_set_threads(int n);
+int orc_get_threads(void);
 void orc_alpha_betas(const orc_ctx *, double *alpha, double *beta /*[L]*/); /* init_alpha_betas(current excluded) */
 
 /* get_cell_log_likelihoods alone (main.rs:541-591) under caller alpha/beta and
