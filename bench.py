@@ -45,6 +45,8 @@ def parse():
                     help="nccl (= RCCL over xGMI, the real path) or gloo: REHEARSAL ONLY — exchanges staged through the host "
                          "so that several ranks can share one GPU (--same-device) on a 1-GPU box")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses cuda:0")
+    ap.add_argument("--opt", action="append", default=[], metavar="KEY=INT",
+                    help="extra cellector_set_option pairs (ablations), e.g. --opt overlap=1")
     ap.add_argument("--no-expected", action="store_true",
                     help="skip the expected_log_likelihood diagnostic column (NOT the reference-equivalent step)")
     return ap.parse_args()
@@ -86,6 +88,9 @@ def main():
     g.set_option("keep_coo", 0)
     g.set_option("engine", args.engine)
     g.set_option("compute_expected", 0 if args.no_expected else 1)
+    for kv in args.opt:
+        k, v = kv.split("=")
+        g.set_option(k, int(v))
     g.set_shard(cb, ce)
 
     def allreduce(t, op=None):

@@ -75,6 +75,15 @@ static void free_matrix(cellector_ctx *c)
     c->em_phase = 0; c->iteration = 0; c->have_iter = false; c->n_excluded_global = 0;
 }
 
+// the side stream gets the lowest priority the device offers: its kernels should only fill slots the main stream's
+// kernels leave idle
+static bool create_side_stream(hipStream_t *out)
+{
+    int least = 0, greatest = 0;
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = 0;
+    return hipStreamCreateWithPriority(out, hipStreamNonBlocking, least) == hipSuccess;
+}
+
 #define REQUIRE(c, cond, msg)                                        \
     do {                                                             \
         if (!(cond)) return ctx_fail((c), CELLECTOR_EINVAL, "%s", msg); \
@@ -107,7 +116,10 @@ cellector_status cellector_create(cellector_ctx **out, int device_id)
               hipMalloc((void **)&c->d_counters, 8 * sizeof(uint32_t)) == hipSuccess &&
               hipMalloc((void **)&c->sel_hist, SEL_T * 256 * sizeof(uint32_t)) == hipSuccess &&
               hipMalloc((void **)&c->sel_state, 4 * SEL_T * sizeof(uint64_t)) == hipSuccess &&
-              hipHostMalloc((void **)&c->h_sel, 8 * sizeof(uint64_t)) == hipSuccess;
+              hipHostMalloc((void **)&c->h_sel, 8 * sizeof(uint64_t)) == hipSuccess &&
+              create_side_stream(&c->side) &&
+              hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) == hipSuccess &&
+              hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) == hipSuccess;
     if (!ok) {
         cellector_destroy(c);
         return CELLECTOR_EDEVICE;
@@ -120,10 +132,14 @@ void cellector_destroy(cellector_ctx *c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
+    if (c->side) (void)hipStreamSynchronize(c->side);
     timer_collect(c);
     free_matrix(c);
     dev_free(c->lf); dev_free(c->d_counters); dev_free(c->sel_hist); dev_free(c->sel_state);
     if (c->h_sel) (void)hipHostFree(c->h_sel);
+    if (c->side) (void)hipStreamDestroy(c->side);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     delete c;
 }
 
@@ -142,6 +158,7 @@ cellector_status cellector_set_option(cellector_ctx *c, const char *key, int64_t
     if (!strcmp(key, "compute_expected")) c->compute_expected = v != 0;
     else if (!strcmp(key, "timing")) c->timing = v != 0;
     else if (!strcmp(key, "keep_coo")) c->keep_coo = v != 0;
+    else if (!strcmp(key, "overlap")) c->overlap = v != 0;
     else if (!strcmp(key, "compact_bits")) {
         if (v != 0 && v != 32) return ctx_fail(c, CELLECTOR_EINVAL, "compact_bits must be 0 (automatic) or 32");
         c->c4_bits_opt = (int)v;

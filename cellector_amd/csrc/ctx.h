@@ -37,6 +37,10 @@ struct KernelTimer {
 struct cellector_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    // side stream for the small overflow kernels that run next to the tile kernel (fork/join with events)
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    int overlap = 0;  // option "overlap": 1 = overflow kernels on the (low-priority) side stream
     mutable std::string err;
 
     // options
@@ -94,6 +98,8 @@ struct cellector_ctx {
     uint32_t *ovf_perm = nullptr;    // [ovf_n] by-cell position -> by-locus position
     double *ovf_tab = nullptr;       // [L][64] per-locus cumulative-log / expected tables for overflow entries
     double2 *ovf_val = nullptr;      // [3][ovf_n] (log-pmf, expected term) of overflow entries, by-locus order
+    uint32_t *ovf_nmask = nullptr;   // [L] which alt+ref totals (4..17) occur among the locus' overflow entries
+    double *ovf_sum = nullptr;       // [3][2][nloc] per-cell sums of the overflow values (ll, expected) per table set
     uint64_t *c4_ptr = nullptr;      // [L+1] compact CSC of regular entries
     uint32_t *c4_ent = nullptr;      // 32-bit entries cell_local | code << 28, or 24-bit cell | code << 20 (c4_bits)
     int c4_bits = 32;

@@ -193,7 +193,7 @@ __global__ __launch_bounds__(T_THREADS, 8) void k_tile_ll(uint32_t nb, uint32_t 
 // overflow entries (n == 0 or n > 3).  Their log-pmf / expected term are evaluated once per pass in LOCUS-major
 // order (k_ovf_values: alpha/beta wave-uniform, so ln B-ratios come from per-locus cumulative log tables held in
 // registers and fetched by cross-lane shuffles), stored as double2 per entry, and then only GATHERED: by the cell
-// side through a precomputed permutation (k_ovf_finalize) and by the locus pass directly (k_locus_ovf).
+// side through a precomputed permutation (k_ovf_cell_sums) and by the locus pass directly (k_locus_stats2).
 // ---------------------------------------------------------------------------------------------------------
 #define OV_NT 18  // cumulative tables cover counts 0..17; larger counts take the generic device_math path
 #define OV_NE 17  // expected terms E(n) tabulated for n = 4..17
@@ -246,12 +246,14 @@ __global__ __launch_bounds__(256) void k_ovf_tables(uint64_t L, const double2 *_
 }
 
 // E(n), n = 4..17, one thread per (locus, n): ln sum_k pmf(k)^2 from the cumulative tables written above
-__global__ void k_ovf_tables_e(uint64_t L, const double *__restrict__ lf, double *__restrict__ otab)
+__global__ void k_ovf_tables_e(uint64_t L, const double *__restrict__ lf, const uint32_t *__restrict__ nmask,
+                               double *__restrict__ otab)
 {
     const uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t l = idx / (OV_NE - 3);
     if (l >= L) return;
     const int n = 4 + (int)(idx % (OV_NE - 3));
+    if (!((nmask[l] >> (n - 4)) & 1u)) return;  // no overflow entry of this locus has this n: E(n) is never read
     double *row = otab + l * OV_ROW;
     if (row[0] < 0.0) return;  // masked locus
     const double labn = row[2 * OV_NT + n];
@@ -328,26 +330,37 @@ __global__ __launch_bounds__(256) void k_ovf_perm(uint64_t L, const uint64_t *__
     }
 }
 
-// cell side: one THREAD per cell row: chunk-group partials in group order, then the row's overflow values in
-// ascending-locus order through the permutation (sequential sums: deterministic), then the normalisation.
+// nmask[l]: bit (n - 4) set iff an overflow entry of locus l has alt+ref == n, 4 <= n <= OV_NE (static)
+__global__ __launch_bounds__(256) void k_ovf_nmask(uint64_t L, const uint64_t *__restrict__ ovc_ptr,
+                                                   const uint64_t *__restrict__ ovc_ent, uint32_t *__restrict__ nmask)
+{
+    const int lane = threadIdx.x & 63;
+    const uint64_t wave0 = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (uint64_t)gridDim.x * 4;
+    for (uint64_t l = wave0; l < L; l += nwaves) {
+        uint32_t m = 0;
+        for (uint64_t i = ovc_ptr[l] + lane; i < ovc_ptr[l + 1]; i += 64) {
+            const uint64_t en = ovc_ent[i];
+            const uint32_t n = ENT_ALT(en) + ENT_REF(en);
+            if (n >= 4u && n <= (uint32_t)OV_NE) m |= 1u << (n - 4u);
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) m |= (uint32_t)__shfl_xor((int)m, off, 64);
+        if (lane == 0) nmask[l] = m;
+    }
+}
+
+// cell side of the overflow entries: one THREAD per cell row sums the row's overflow values in ascending-locus order
+// through the permutation (sequential: deterministic and independent of the sharding).  Runs on the side stream next
+// to the tile kernel; k_cell_finalize adds the result to the tile partials.
 template <bool EXPECTED>
-__global__ __launch_bounds__(256) void k_ovf_finalize(uint64_t n_rows, const uint64_t *__restrict__ ovf_ptr,
-                                                      const uint32_t *__restrict__ perm,
-                                                      const double2 *__restrict__ val, uint32_t groups, uint64_t npad,
-                                                      const double *__restrict__ part_ll,
-                                                      const double *__restrict__ part_ell,
-                                                      const uint64_t *__restrict__ csr_ptr,
-                                                      const uint32_t *__restrict__ masked_cnt, double *__restrict__ ll,
-                                                      double *__restrict__ ell, double *__restrict__ nloci,
-                                                      double *__restrict__ norm_out)
+__global__ __launch_bounds__(256) void k_ovf_cell_sums(uint64_t n_rows, const uint64_t *__restrict__ ovf_ptr,
+                                                       const uint32_t *__restrict__ perm,
+                                                       const double2 *__restrict__ val, double *__restrict__ o_ll,
+                                                       double *__restrict__ o_ell)
 {
     const uint64_t row = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (row >= n_rows) return;
     double s = 0.0, e = 0.0;
-    for (uint32_t g = 0; g < groups; g++) {
-        s += part_ll[(uint64_t)g * npad + row];
-        if (EXPECTED) e += part_ell[(uint64_t)g * npad + row];
-    }
     const uint64_t beg = ovf_ptr[row], end = ovf_ptr[row + 1];
     uint64_t i = beg;
     for (; i + 4 <= end; i += 4) {  // four independent gathers in flight
@@ -359,6 +372,33 @@ __global__ __launch_bounds__(256) void k_ovf_finalize(uint64_t n_rows, const uin
         const double2 v = val[perm[i]];
         s += v.x;
         if (EXPECTED) e += v.y;
+    }
+    o_ll[row] = s;
+    if (EXPECTED) o_ell[row] = e;
+}
+
+// chunk-group partials in group order, then the row's overflow sum, then the normalisation (main.rs:314-323)
+template <bool EXPECTED>
+__global__ __launch_bounds__(256) void k_cell_finalize(uint64_t n_rows, uint32_t groups, uint64_t npad,
+                                                       const double *__restrict__ part_ll,
+                                                       const double *__restrict__ part_ell,
+                                                       const double *__restrict__ o_ll /*null: no overflow entries*/,
+                                                       const double *__restrict__ o_ell,
+                                                       const uint64_t *__restrict__ csr_ptr,
+                                                       const uint32_t *__restrict__ masked_cnt, double *__restrict__ ll,
+                                                       double *__restrict__ ell, double *__restrict__ nloci,
+                                                       double *__restrict__ norm_out)
+{
+    const uint64_t row = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= n_rows) return;
+    double s = 0.0, e = 0.0;
+    for (uint32_t g = 0; g < groups; g++) {
+        s += part_ll[(uint64_t)g * npad + row];
+        if (EXPECTED) e += part_ell[(uint64_t)g * npad + row];
+    }
+    if (o_ll) {
+        s += o_ll[row];
+        if (EXPECTED) e += o_ell[row];
     }
     const double cnt = (double)((csr_ptr[row + 1] - csr_ptr[row]) - (uint64_t)masked_cnt[row]);
     ll[row] = s;
@@ -414,7 +454,11 @@ __global__ __launch_bounds__(LS_THREADS) void k_locus_stats2(uint64_t L, uint32_
                                                              const uint32_t *__restrict__ flag_bits,
                                                              const uint32_t *__restrict__ hist_all,
                                                              const double *__restrict__ tab,
-                                                             const uint8_t *__restrict__ mask, double *__restrict__ out)
+                                                             const uint8_t *__restrict__ mask,
+                                                             const uint64_t *__restrict__ ovc_ptr /*null: no overflow*/,
+                                                             const uint64_t *__restrict__ ovc_ent,
+                                                             const double2 *__restrict__ ovf_val,
+                                                             double *__restrict__ out)
 {
     extern __shared__ uint32_t s_bits[];
     __shared__ uint32_t s_whist[LS_THREADS / 64][16];
@@ -431,6 +475,22 @@ __global__ __launch_bounds__(LS_THREADS) void k_locus_stats2(uint64_t L, uint32_
         // columns are padded to groups of four entries (code 15 = no entry): 16 bytes at 32 bits, 12 bytes at 24 bits
         const uint64_t vbeg = c4_ptr[l] >> 2, nvec = (c4_ptr[l + 1] >> 2) - vbeg;
         const uint32_t *wp = c4_ent + vbeg * (EB == 32 ? 4 : 3);
+        // this locus' overflow entries (alt+ref == 0 or > T_K; ~1 %): their stored log-pmfs are only gathered.  The
+        // first 64 are requested now and consumed after the column has been streamed.
+        uint64_t obeg = 0, oend = 0, o_en = 0, o_en2 = 0;
+        double o_lp = 0.0, o_lp2 = 0.0;
+        if (ovc_ptr) {
+            obeg = ovc_ptr[l];
+            oend = ovc_ptr[l + 1];
+            if (obeg + lane < oend) {
+                o_en = ovc_ent[obeg + lane];
+                o_lp = ovf_val[obeg + lane].x;
+            }
+            if (obeg + 64 + lane < oend) {
+                o_en2 = ovc_ent[obeg + 64 + lane];
+                o_lp2 = ovf_val[obeg + 64 + lane].x;
+            }
+        }
         // minority entries are few: they vote into this wave's 16-bin LDS histogram (integer atomics: exact)
         for (uint64_t i0 = 0; i0 < nvec; i0 += 4 * 64) {
             // four independent loads per lane in flight: the pass is a pure stream
@@ -489,48 +549,38 @@ __global__ __launch_bounds__(LS_THREADS) void k_locus_stats2(uint64_t L, uint32_
         nmin = wave_sum_u32(nmin);
         amin = wave_sum_u32(amin);
         rmin = wave_sum_u32(rmin);
-        if (lane == 0) {
-            out[LB_CONTRIB_MIN * L + l] = cmin;
-            out[LB_CONTRIB_MAJ * L + l] = cmaj;
-            out[LB_CELLS_MIN * L + l] = live ? (double)nmin : 0.0;
-            out[LB_ALT_MIN * L + l] = (double)amin;
-            out[LB_REF_MIN * L + l] = (double)rmin;
-        }
-    }
-}
-
-// overflow part of the locus pass: stored values, adds into the planes written by k_locus_stats2
-__global__ __launch_bounds__(256) void k_locus_ovf(uint64_t L, const uint64_t *__restrict__ col_ptr,
-                                                   const uint64_t *__restrict__ ent, const double2 *__restrict__ val,
-                                                   const uint8_t *__restrict__ mask, const uint8_t *__restrict__ flags,
-                                                   double *__restrict__ out)
-{
-    const int lane = threadIdx.x & 63;
-    const uint64_t wave0 = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (uint64_t)gridDim.x * 4;
-    for (uint64_t l = wave0; l < L; l += nwaves) {
-        const uint64_t beg = col_ptr[l], end = col_ptr[l + 1];
-        if (end == beg) continue;
-        const bool live = mask[l] != 0;
-        double cmin = 0.0, cmaj = 0.0;
-        uint32_t nmin = 0;
-        uint64_t amin = 0, rmin = 0;
-        for (uint64_t i = beg + lane; i < end; i += 64) {
-            const uint64_t en = ent[i];
-            const bool minority = flags[ENT_IDX(en)] != 0;
-            if (minority) { amin += ENT_ALT(en); rmin += ENT_REF(en); }
-            if (live) {
-                const double lp = val[i].x;
-                if (minority) { cmin += lp; nmin++; } else cmaj += lp;
+        // overflow part (wave-uniform trip count); same sums as the regular part, added once per plane
+        double o_cmin = 0.0, o_cmaj = 0.0;
+        uint32_t o_nmin = 0;
+        uint64_t o_amin = 0, o_rmin = 0;
+        for (uint64_t i0 = obeg; i0 < oend; i0 += 64) {
+            const uint64_t i = i0 + lane;
+            if (i0 == obeg + 64) {
+                o_en = o_en2;
+                o_lp = o_lp2;
+            } else if (i0 != obeg && i < oend) {
+                o_en = ovc_ent[i];
+                o_lp = ovf_val[i].x;
+            }
+            if (i < oend) {
+                const uint32_t cell = ENT_IDX(o_en);
+                const bool minority = ((bits[cell >> 5] >> (cell & 31)) & 1u) != 0;
+                if (minority) { o_amin += ENT_ALT(o_en); o_rmin += ENT_REF(o_en); }
+                if (live) {
+                    if (minority) { o_cmin += o_lp; o_nmin++; } else o_cmaj += o_lp;
+                }
             }
         }
-        cmin = wave_sum(cmin); cmaj = wave_sum(cmaj);
-        nmin = wave_sum_u32(nmin); amin = wave_sum_u64(amin); rmin = wave_sum_u64(rmin);
+        if (oend != obeg) {
+            o_cmin = wave_sum(o_cmin); o_cmaj = wave_sum(o_cmaj);
+            o_nmin = wave_sum_u32(o_nmin); o_amin = wave_sum_u64(o_amin); o_rmin = wave_sum_u64(o_rmin);
+        }
         if (lane == 0) {
-            out[LB_CONTRIB_MIN * L + l] += cmin;
-            out[LB_CONTRIB_MAJ * L + l] += cmaj;
-            out[LB_CELLS_MIN * L + l] += (double)nmin;
-            out[LB_ALT_MIN * L + l] += (double)amin;
-            out[LB_REF_MIN * L + l] += (double)rmin;
+            out[LB_CONTRIB_MIN * L + l] = cmin + o_cmin;
+            out[LB_CONTRIB_MAJ * L + l] = cmaj + o_cmaj;
+            out[LB_CELLS_MIN * L + l] = (live ? (double)nmin : 0.0) + (double)o_nmin;
+            out[LB_ALT_MIN * L + l] = (double)amin + (double)o_amin;
+            out[LB_REF_MIN * L + l] = (double)rmin + (double)o_rmin;
         }
     }
 }
@@ -582,10 +632,8 @@ __global__ void k_ab_posterior3(uint64_t L, const double *__restrict__ s_alt, co
     o[0] = a_min; o[1] = b_min; o[2] = a_maj; o[3] = b_maj; o[4] = a_dbl; o[5] = b_dbl; o[6] = 0.0; o[7] = 0.0;
 }
 
-__global__ __launch_bounds__(256) void k_posterior_finalize(uint64_t n_rows, const uint64_t *__restrict__ ovf_ptr,
-                                                            const uint32_t *__restrict__ perm,
-                                                            const double2 *__restrict__ val /*[3][ovf_n]*/,
-                                                            uint64_t ovf_n, uint32_t groups, uint64_t npad,
+__global__ __launch_bounds__(256) void k_posterior_finalize(uint64_t n_rows, const double *__restrict__ osum /*[3][2][n_rows] or null*/,
+                                                            uint32_t groups, uint64_t npad,
                                                             const double *__restrict__ part /*[3][2][G][npad]*/,
                                                             double lp_min, double lp_maj, double lp_dbl,
                                                             double *__restrict__ post)
@@ -599,12 +647,10 @@ __global__ __launch_bounds__(256) void k_posterior_finalize(uint64_t n_rows, con
         s1 += part[set_stride + (uint64_t)g * npad + row];
         s2 += part[2 * set_stride + (uint64_t)g * npad + row];
     }
-    const uint64_t beg = ovf_ptr[row], end = ovf_ptr[row + 1];
-    for (uint64_t i = beg; i < end; i++) {
-        const uint64_t p = perm[i];
-        s0 += val[p].x;
-        s1 += val[ovf_n + p].x;
-        s2 += val[2 * ovf_n + p].x;
+    if (osum) {
+        s0 += osum[row];
+        s1 += osum[2 * n_rows + row];
+        s2 += osum[4 * n_rows + row];
     }
     const double s_min = s0, s_maj = s1, s_dbl = s2;
     const double log_num = lp_min + s_min;                       // main.rs:267
@@ -764,6 +810,7 @@ void tiled_free(cellector_ctx *c)
     dev_free(c->c4_ptr); dev_free(c->c4_ent); dev_free(c->ovc_ptr); dev_free(c->ovc_ent);
     dev_free(c->hist_all); dev_free(c->tab); dev_free(c->part); dev_free(c->ab3);
     dev_free(c->masked_cnt); dev_free(c->flag_bits); dev_free(c->ovf_perm); dev_free(c->ovf_val); dev_free(c->ovf_tab);
+    dev_free(c->ovf_sum); dev_free(c->ovf_nmask);
     c->tiled_ready = false;
     c->ovf_n = 0; c->n_masked_loci = 0;
 }
@@ -854,10 +901,14 @@ cellector_status tiled_build(cellector_ctx *c)
     if (c->ovf_n >= (1ull << 32)) return ctx_fail(c, CELLECTOR_EINVAL, "tiled engine: more than 2^32 overflow entries per shard");
     CHK(dev_alloc(c, &c->ovf_perm, c->ovf_n));
     CHK(dev_alloc(c, &c->ovf_val, 3 * c->ovf_n));
+    CHK(dev_alloc(c, &c->ovf_sum, 3 * 2 * nloc));
     CHK(dev_alloc(c, &c->ovf_tab, L * OV_ROW));
-    if (L && c->ovf_n)
+    CHK(dev_alloc(c, &c->ovf_nmask, L));
+    if (L && c->ovf_n) {
         hipLaunchKernelGGL(k_ovf_perm, dim3(gcap(L, 4)), dim3(256), 0, c->stream, L, c->ovc_ptr, c->ovc_ent, c->ovf_ptr,
                            c->ovf_ent, c->ovf_perm);
+        hipLaunchKernelGGL(k_ovf_nmask, dim3(gcap(L, 4)), dim3(256), 0, c->stream, L, c->ovc_ptr, c->ovc_ent, c->ovf_nmask);
+    }
     HIPCHK(c, hipGetLastError());
 
     // ---- per-iteration workspaces
@@ -874,25 +925,52 @@ cellector_status tiled_build(cellector_ctx *c)
     return CELLECTOR_OK;
 }
 
+// Overflow side of one pass: tables -> per-entry values (locus-major) -> per-cell sums.  Launched on the side stream so
+// that these small, latency-bound kernels run next to the tile kernel instead of in front of it.
+static void launch_overflow_pass(cellector_ctx *c, hipStream_t st, const double2 *ab, int set, bool expected)
+{
+    double2 *val = c->ovf_val + (uint64_t)set * c->ovf_n;
+    double *o_ll = c->ovf_sum + (uint64_t)set * 2 * c->nloc, *o_ell = o_ll + c->nloc;
+    hipLaunchKernelGGL(k_ovf_tables, dim3(gcap(c->L * 32, 256, 0x7fffffffu)), dim3(256), 0, st, c->L, ab, c->ovf_tab);
+    if (expected) {
+        hipLaunchKernelGGL(k_ovf_tables_e, dim3(gcap(c->L * (OV_NE - 3), 256, 0x7fffffffu)), dim3(256), 0, st, c->L, c->lf,
+                           c->ovf_nmask, c->ovf_tab);
+        hipLaunchKernelGGL(k_ovf_values<true>, dim3(gcap(c->L, 4, 4096)), dim3(256), 0, st, c->L, c->ovc_ptr, c->ovc_ent, ab, c->lf,
+                           c->ovf_tab, val);
+        hipLaunchKernelGGL(k_ovf_cell_sums<true>, dim3(gcap(c->nloc, 256, 0x7fffffffu)), dim3(256), 0, st, c->nloc, c->ovf_ptr,
+                           c->ovf_perm, val, o_ll, o_ell);
+    } else {
+        hipLaunchKernelGGL(k_ovf_values<false>, dim3(gcap(c->L, 4, 4096)), dim3(256), 0, st, c->L, c->ovc_ptr, c->ovc_ent, ab, c->lf,
+                           c->ovf_tab, val);
+        hipLaunchKernelGGL(k_ovf_cell_sums<false>, dim3(gcap(c->nloc, 256, 0x7fffffffu)), dim3(256), 0, st, c->nloc, c->ovf_ptr,
+                           c->ovf_perm, val, o_ll, o_ell);
+    }
+}
+
+static bool have_overflow(const cellector_ctx *c) { return c->ovf_n != 0 && c->L != 0 && c->nloc != 0; }
+
+// fork: the side stream starts after everything already queued on the main stream (alpha/beta are ready there)
+static cellector_status side_fork(cellector_ctx *c)
+{
+    HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
+    HIPCHK(c, hipStreamWaitEvent(c->side, c->ev_fork, 0));
+    return CELLECTOR_OK;
+}
+// join: the main stream continues after everything queued on the side stream
+static cellector_status side_join(cellector_ctx *c)
+{
+    HIPCHK(c, hipEventRecord(c->ev_join, c->side));
+    HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
+    return CELLECTOR_OK;
+}
+
+// table build + tile kernel of one pass on the main stream
 static cellector_status run_tile_pass(cellector_ctx *c, const double2 *ab, int set, bool expected)
 {
     const uint64_t tab_elems = (uint64_t)c->t_nj * T_W * T_BL;
     double *tab = c->tab + (uint64_t)set * tab_elems;
     double *part_ll = c->part + (uint64_t)set * 2 * c->t_groups * c->t_npad;
     double *part_ell = part_ll + (uint64_t)c->t_groups * c->t_npad;
-    if (c->ovf_n && c->L) {
-        double2 *val = c->ovf_val + (uint64_t)set * c->ovf_n;
-        hipLaunchKernelGGL(k_ovf_tables, dim3(gcap(c->L * 32, 256, 0x7fffffffu)), dim3(256), 0, c->stream, c->L, ab, c->ovf_tab);
-        if (expected)
-            hipLaunchKernelGGL(k_ovf_tables_e, dim3(gcap(c->L * (OV_NE - 3), 256, 0x7fffffffu)), dim3(256), 0, c->stream, c->L,
-                               c->lf, c->ovf_tab);
-        if (expected)
-            hipLaunchKernelGGL(k_ovf_values<true>, dim3(gcap(c->L, 4)), dim3(256), 0, c->stream, c->L, c->ovc_ptr, c->ovc_ent,
-                               ab, c->lf, c->ovf_tab, val);
-        else
-            hipLaunchKernelGGL(k_ovf_values<false>, dim3(gcap(c->L, 4)), dim3(256), 0, c->stream, c->L, c->ovc_ptr, c->ovc_ent,
-                               ab, c->lf, c->ovf_tab, val);
-    }
     hipLaunchKernelGGL(k_build_tables, dim3(gcap((uint64_t)c->t_nj * T_BL, 256)), dim3(256), 0, c->stream, c->L, c->t_nj,
                        ab, c->lf, tab, expected ? 1 : 0);
     // several cell blocks per workgroup amortise the table staging; with few blocks (small shard) prefer more workgroups
@@ -918,17 +996,22 @@ cellector_status tiled_cell_pass(cellector_ctx *c, const double2 *ab, double *no
 {
     if (c->nloc == 0) return CELLECTOR_OK;
     timer_begin(c, CELLECTOR_K_CELL_LL);
+    const bool ovf = have_overflow(c);
+    if (ovf) {
+        if (c->overlap) CHK(side_fork(c));
+        launch_overflow_pass(c, c->overlap ? c->side : c->stream, ab, 0, c->compute_expected);
+    }
     CHK(run_tile_pass(c, ab, 0, c->compute_expected));
+    if (ovf && c->overlap) CHK(side_join(c));
     double *part_ll = c->part, *part_ell = c->part + (uint64_t)c->t_groups * c->t_npad;
+    const double *o_ll = ovf ? c->ovf_sum : nullptr, *o_ell = ovf ? c->ovf_sum + c->nloc : nullptr;
     const unsigned grid = gcap(c->nloc, 256, 0x7fffffffu);
     if (c->compute_expected)
-        hipLaunchKernelGGL(k_ovf_finalize<true>, dim3(grid), dim3(256), 0, c->stream, c->nloc, c->ovf_ptr, c->ovf_perm,
-                           c->ovf_val, c->t_groups, c->t_npad, part_ll, part_ell, c->csr_ptr, c->masked_cnt, c->ll, c->ell,
-                           c->nloci, norm_out);
+        hipLaunchKernelGGL(k_cell_finalize<true>, dim3(grid), dim3(256), 0, c->stream, c->nloc, c->t_groups, c->t_npad, part_ll,
+                           part_ell, o_ll, o_ell, c->csr_ptr, c->masked_cnt, c->ll, c->ell, c->nloci, norm_out);
     else
-        hipLaunchKernelGGL(k_ovf_finalize<false>, dim3(grid), dim3(256), 0, c->stream, c->nloc, c->ovf_ptr, c->ovf_perm,
-                           c->ovf_val, c->t_groups, c->t_npad, part_ll, part_ell, c->csr_ptr, c->masked_cnt, c->ll, c->ell,
-                           c->nloci, norm_out);
+        hipLaunchKernelGGL(k_cell_finalize<false>, dim3(grid), dim3(256), 0, c->stream, c->nloc, c->t_groups, c->t_npad, part_ll,
+                           part_ell, o_ll, o_ell, c->csr_ptr, c->masked_cnt, c->ll, c->ell, c->nloci, norm_out);
     timer_end(c, CELLECTOR_K_CELL_LL);
     HIPCHK(c, hipGetLastError());
     return CELLECTOR_OK;
@@ -950,7 +1033,8 @@ cellector_status tiled_locus_pass(cellector_ctx *c)
     if (grid > need) grid = (unsigned)(need ? need : 1);
 #define LAUNCH_LS(INLDS, EBV, GRID, LDSB)                                                                              \
     hipLaunchKernelGGL((k_locus_stats2<INLDS, EBV>), dim3(GRID), dim3(LS_THREADS), LDSB, c->stream, c->L, words, c->c4_ptr, \
-                       c->c4_ent, c->flag_bits, c->hist_all, c->tab, c->mask, c->x_locus)
+                       c->c4_ent, c->flag_bits, c->hist_all, c->tab, c->mask, c->ovf_n ? c->ovc_ptr : (const uint64_t *)nullptr,  \
+                       c->ovc_ent, c->ovf_val, c->x_locus)
     if (lds <= 128 * 1024) {
         const int lb = (int)(lds ? lds : 4);
         if (c->c4_bits == 24) {
@@ -964,9 +1048,6 @@ cellector_status tiled_locus_pass(cellector_ctx *c)
         LAUNCH_LS(false, 32, grid * 2, 4);  // more than 2^20 cells per shard: 32-bit entries, bitmask read from L2
     }
 #undef LAUNCH_LS
-    if (c->ovf_n)
-        hipLaunchKernelGGL(k_locus_ovf, dim3(gcap(c->L, 4)), dim3(256), 0, c->stream, c->L, c->ovc_ptr, c->ovc_ent,
-                           c->ovf_val, c->mask, c->flags_new, c->x_locus);
     timer_end(c, CELLECTOR_K_LOCUS_STATS);
     HIPCHK(c, hipGetLastError());
     return CELLECTOR_OK;
@@ -995,9 +1076,16 @@ cellector_status tiled_posteriors(cellector_ctx *c, double mf0, double lp_min, d
     HIPCHK(c, hipGetLastError());
     if (c->nloc == 0) return CELLECTOR_OK;
     timer_begin(c, CELLECTOR_K_POSTERIOR);
+    const bool ovf = have_overflow(c);
+    if (ovf) {
+        if (c->overlap) CHK(side_fork(c));
+        for (int set = 0; set < 3; set++)
+            launch_overflow_pass(c, c->overlap ? c->side : c->stream, c->ab3 + (uint64_t)set * L, set, false);
+    }
     for (int set = 0; set < 3; set++) CHK(run_tile_pass(c, c->ab3 + (uint64_t)set * L, set, false));
-    hipLaunchKernelGGL(k_posterior_finalize, dim3(gcap(c->nloc, 256, 0x7fffffffu)), dim3(256), 0, c->stream, c->nloc, c->ovf_ptr,
-                       c->ovf_perm, c->ovf_val, c->ovf_n, c->t_groups, c->t_npad, c->part, lp_min, lp_maj, lp_dbl, c->post);
+    if (ovf && c->overlap) CHK(side_join(c));
+    hipLaunchKernelGGL(k_posterior_finalize, dim3(gcap(c->nloc, 256, 0x7fffffffu)), dim3(256), 0, c->stream, c->nloc,
+                       ovf ? c->ovf_sum : (const double *)nullptr, c->t_groups, c->t_npad, c->part, lp_min, lp_maj, lp_dbl, c->post);
     timer_end(c, CELLECTOR_K_POSTERIOR);
     HIPCHK(c, hipGetLastError());
     return CELLECTOR_OK;
