@@ -663,15 +663,7 @@ cellector_status cellector_engine_info(const cellector_ctx *c, cellector_engine_
         o->nnz_regular = c->nnz - c->ovf_n;
         o->nnz_overflow = c->ovf_n;
         o->cell_blocks = c->t_nb; o->locus_chunks = c->t_nj; o->chunk_groups = c->t_groups;
-        uint64_t elems = 0;
-        cellector_status s = CELLECTOR_OK;
-        {
-            hipError_t e = hipSetDevice(c->device);
-            if (e == hipSuccess)
-                e = hipMemcpy(&elems, c->tile_ptr + (uint64_t)c->t_nb * c->t_nj, 8, hipMemcpyDeviceToHost);
-            if (e != hipSuccess) s = ctx_fail(c, CELLECTOR_EDEVICE, "engine_info: %s", hipGetErrorString(e));
-        }
-        CHK(s);
+        const uint64_t elems = c->t_elems + (uint64_t)c->t_nb * c->t_nj * 128;  // slices + slice headers (u16 units)
         o->tile_bytes = elems * 2;
     }
     return CELLECTOR_OK;

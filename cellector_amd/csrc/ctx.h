@@ -92,7 +92,11 @@ struct cellector_ctx {
     uint32_t t_nb = 0, t_nj = 0, t_groups = 0, t_cpg = 0;  // cell blocks, locus chunks, chunk groups, chunks/group
     uint64_t t_npad = 0;             // nb * T_BC
     uint64_t *tile_ptr = nullptr;    // [nb*nj+1] offsets into tiles, in u16 elements (multiples of 8)
-    uint16_t *tiles = nullptr;       // per tile: [T_BC counts][entries code<<9|locus_in_chunk]
+    uint16_t *tiles = nullptr;       // entry stream: per tile its u16 entries code<<9 | locus_in_chunk, cells in order
+    uint16_t *thdr = nullptr;        // [nb*nj][T_HDR] tile headers (per-wave base + per-cell offsets)
+    uint64_t t_elems = 0;            // entries (u16) in the stream, padding included
+    double *tab_em = nullptr;        // table the last EM cell pass built (the locus pass reads its log-pmfs)
+    int tab_em_stride = 1;           // 2 when that table holds (log-pmf, expected) pairs
     uint64_t *ovf_ptr = nullptr, *ovf_ent = nullptr;    // overflow CSR (n == 0 or n > 3), packed like csr_ent
     uint64_t ovf_n = 0;
     uint32_t *ovf_perm = nullptr;    // [ovf_n] by-cell position -> by-locus position

@@ -1,39 +1,48 @@
 // Engine v2: table-driven passes over a tiled 16-bit matrix layout (gfx950, wave64).
 //
 // Observation: under one (alpha_l, beta_l) the log-pmf of an entry depends only on (alt, ref), and vartrix counts
-// are tiny (n = alt+ref <= 3 for ~97 % of entries).  So per EM iteration and locus we tabulate the 9 log-pmfs of
-// n = 1..3 and the 3 expected terms ("tables", 12 f64 per locus) and the matrix passes become pure table lookups:
+// are tiny (n = alt+ref <= 4 for ~99 % of entries).  So per EM iteration and locus we tabulate the 14 log-pmfs of
+// n = 1..4 and the 4 expected terms and the matrix passes become pure table lookups:
 //
-//   cell pass   (get_cell_log_likelihoods, main.rs:541-591): the matrix is cut into (1024-cell block x 512-locus
-//               chunk) tiles; a tile is [1024 u16 per-cell counts][u16 entries = code<<9 | locus_in_chunk], cells in
-//               order, loci ascending inside a cell.  A 512-thread workgroup owns one cell block and walks a group
-//               of chunks: stage the chunk's table (48 KB) and the tile in LDS, then every lane walks the segments of
-//               its own two cells and accumulates in registers.  No transcendental, no atomics, ~2.4 B of HBM
-//               traffic per entry, and each cell's sum runs in ascending-locus order like the reference's.
-//   locus pass  (get_locus_log_likelihoods, main.rs:368-420): compact CSC of u32 entries (cell | code<<28); the new
-//               exclusion set is a bitmask staged in LDS; a wave per locus counts minority entries per code with
-//               ballots; contributions are count x table value; the majority side is (static histogram - minority).
-//   overflow    entries with n == 0 or n > 3 (~3 %) live in a small CSR/CSC in the v1 packed format and take the
-//               v1 arithmetic (device_math.h); the finalize kernels add them in a fixed order.
+//   cell pass   (get_cell_log_likelihoods, main.rs:541-591): the matrix is cut into (1024-cell block x 384-locus
+//               chunk) tiles, stored in a sliced-ELLPACK form with a sorting window of one tile (SELL-64-1024): the
+//               cells of a tile are ordered by their entry count, every 64 of them form a slice whose rows (one per
+//               cell: cell id + entries) are padded to the slice's longest cell, so that all lanes of a wave run the
+//               SAME number of lookups — no divergence and ~10 % padding instead of the ~55 % idle lanes of a
+//               cell-per-lane walk in file order — and a lane fetches its row with one or two 16-byte loads.
+//               A u16 entry is the table index code * 384 + locus_in_chunk; padding points at a row of zeros.
+//               A 1024-thread workgroup owns four cell blocks and a group of chunks: the chunk's table lives in LDS as
+//               (log-pmf, expected term) PAIRS so that one ds_read_b128 serves both sums; a lane keeps its cell's
+//               entries of the tile in registers (prefetched two tiles ahead) and adds the tile's sum to the cell's
+//               accumulator in LDS (the lane <-> cell assignment changes from tile to tile).  The kernel is bound by
+//               the LDS pipe (random 16-byte lookups, ~12 clk per wave instruction: tools/probe/lds_probe.hip).
+//               No transcendental, no atomics; a cell's sum runs over its chunks in order and inside a chunk in
+//               ascending-locus order: bit-deterministic and independent of the sharding.
+//   locus pass  (get_locus_log_likelihoods, main.rs:368-420): compact CSC of 24/32-bit entries (cell | code); the new
+//               exclusion set is a bitmask staged in LDS; a wave per locus counts minority entries per code;
+//               contributions are count x table value; the majority side is (static histogram - minority).
+//   overflow    entries with n == 0 or n > 4 (~1 %) live in a small CSR/CSC in the v1 packed format; their values are
+//               computed once per pass in locus-major order and gathered.
+#include <type_traits>
+
 #include "ctx.h"
 #include "device_math.h"
 
 #define T_K 4           // entries with 1 <= alt+ref <= T_K are "regular": log-pmf and expected term come from tables
 #define T_NCODE 14      // (alt, ref) combinations with 1 <= n <= T_K: K(K+3)/2
-#define T_W 18          // table doubles per locus: T_NCODE log-pmfs + T_K expected terms
-#define T_BL 384        // loci per chunk: T_W * T_BL * 8 = 54 KB of LDS
-#define T_BC 1024       // cells per block == threads per workgroup: one lane per cell
+#define T_ROWS 15       // table rows per chunk: the T_NCODE codes and one row of zeros for the padding entries
+#define T_BL 384        // loci per chunk: the paired table is T_ROWS * T_BL * 16 B = 90 KB of LDS
+#define T_BC 1024       // cells per block == threads per workgroup
 #define T_THREADS 1024
-#define T_SB_MAX 4      // cell blocks per workgroup sharing one staged table (1, 2 or 4: chosen per launch)
-#define T_CAP 4096      // entries of one tile staged per window: 4 per lane (8 KB)
-#define T_GROUPS 8
-#define T_HDR 1088      // tile header in u16 units: 16 x {u32 wave base, u32 wave total} then 1024 x u16 offsets
-                        // (exclusive, relative to the base of the cell's wave: < 64 * T_BL)
-#define T_NP ((T_W * T_BL / 2 + T_THREADS - 1) / T_THREADS)  // double2 table prefetch registers per lane
-// tile entry (u16): bits 0..3 code, 4..12 locus_in_chunk, 13..14 n-1
-#define TE_CODE(e) ((e) & 15u)
-#define TE_LOC(e) (((e) >> 4) & 511u)
-#define TE_NM1(e) ((e) >> 13)
+#define T_SB_MAX 4      // cell blocks per workgroup sharing one staged table (2 or 4: chosen per launch)
+#define T_GROUPS 8      // chunk groups (== XCDs: the workgroups of a group run on one XCD and share its L2)
+#define T_NE 15         // entries per cell of a slice held in registers (two 16-byte loads); longer slices: slow path
+#define T_NULL ((uint16_t)(T_NCODE * T_BL))  // padding entry: first element of the zero row
+// A slice in `tiles` is 64 rows of K+1 u16 (K odd): row i = [cell (0..1023) that lane i works for, K entries of that cell,
+// padded with T_NULL].  Tile header (fixed stride, in u16 units): 16 slices x {u64 first u16 of the slice in `tiles`,
+// u32 K, u32 pad}.
+#define T_HDR 128
+#define TAB_ELEMS ((uint64_t)T_ROWS * T_BL)  // table elements per chunk
 
 // code = n(n+1)/2 - 1 + ref:  n=1: (1,0)(0,1)  n=2: (2,0)(1,1)(0,2)  n=3: (3,0)..(0,3)  n=4: (4,0)..(0,4)
 __device__ __constant__ uint8_t T_A_OF[T_NCODE] = {1, 0, 2, 1, 0, 3, 2, 1, 0, 4, 3, 2, 1, 0};
@@ -51,140 +60,227 @@ __device__ __forceinline__ uint32_t ent_code(uint64_t e)
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// tables: tab[j][w][loc], w = 0..8 log-pmf of code w, w = 9..11 expected term of n = w-8; zero rows for masked
-// loci (alpha < 0) and for the padding beyond L.
+// tables, laid out [chunk][row][locus_in_chunk] so that a chunk is one contiguous block the tile kernel copies
+// straight into LDS.  PAIRS: element = (log-pmf of the code, expected term of the code's n) as double2; else the
+// log-pmf alone.  Zero for masked loci (alpha < 0), for the padding beyond L and in row T_NCODE.
 // ---------------------------------------------------------------------------------------------------------
+template <bool PAIRS>
 __global__ void k_build_tables(uint64_t L, uint32_t nj, const double2 *__restrict__ ab, const double *__restrict__ lf,
-                               double *__restrict__ tab, int expected)
+                               double *__restrict__ tab)
 {
     const uint64_t l = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (l >= (uint64_t)nj * T_BL) return;
-    double *row = tab + (l / T_BL) * (uint64_t)(T_W * T_BL) + (l % T_BL);
     double2 p = make_double2(-1.0, -1.0);
     if (l < L) p = ab[l];
     const bool live = p.x >= 0.0;
+    double ex[T_K + 1];
 #pragma unroll
-    for (int w = 0; w < T_NCODE; w++)
-        row[w * T_BL] = live ? dm_log_bb_pmf(lf, p.x, p.y, T_A_OF[w], T_R_OF[w]) : 0.0;
+    for (int n = 1; n <= T_K; n++) ex[n] = (PAIRS && live) ? dm_expected_log_pmf(lf, p.x, p.y, (uint32_t)n) : 0.0;
+    const uint64_t base = (l / T_BL) * TAB_ELEMS + (l % T_BL);
 #pragma unroll
-    for (int n = 1; n <= T_K; n++)
-        row[(T_NCODE + n - 1) * T_BL] = (live && expected) ? dm_expected_log_pmf(lf, p.x, p.y, (uint32_t)n) : 0.0;
+    for (int w = 0; w < T_ROWS; w++) {
+        const double t = (live && w < T_NCODE) ? dm_log_bb_pmf(lf, p.x, p.y, T_A_OF[w % T_NCODE], T_R_OF[w % T_NCODE]) : 0.0;
+        const double e = w < T_NCODE ? ex[T_A_OF[w % T_NCODE] + T_R_OF[w % T_NCODE]] : 0.0;
+        if (PAIRS) reinterpret_cast<double2 *>(tab)[base + (uint64_t)w * T_BL] = make_double2(t, e);
+        else tab[base + (uint64_t)w * T_BL] = t;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------
 // cell pass over the tiles
 // ---------------------------------------------------------------------------------------------------------
+#ifndef TILE_ABL
+#define TILE_ABL 0  // ablation builds of the tile kernel (tools/gpu_ab.sh): 1 no lookups, 2 no entry loads, 3 no table re-staging
+#endif
 // Workgroup barrier that waits for this wave's LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it would wait
-// for the prefetch loads issued just before it and make them synchronous; here they stay in flight across the barrier
-// and the compiler's own s_waitcnt guards their first use one step later.
+// for the prefetch loads in flight and make them synchronous.
 #define TILE_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
+struct __attribute__((packed, aligned(4))) tile_u4 { uint32_t x, y, z, w; };  // 16-byte load at a 4-byte aligned address
+
 template <bool EXPECTED, int T_SB>
-__global__ __launch_bounds__(T_THREADS, 8) void k_tile_ll(uint32_t nb, uint32_t nj, uint32_t cpg,
-                                                          const uint64_t *__restrict__ tile_ptr,
+__global__ __launch_bounds__(T_THREADS, 4) void k_tile_ll(uint32_t nb, uint32_t nj, uint32_t cpg, uint32_t groups,
+                                                          const uint16_t *__restrict__ thdr,
                                                           const uint16_t *__restrict__ tiles,
                                                           const double *__restrict__ tab, uint64_t npad,
                                                           double *__restrict__ part_ll, double *__restrict__ part_ell)
 {
-    // A workgroup owns T_SB consecutive 1024-cell blocks (one lane per cell of each) and one group of locus chunks.
-    // Per chunk the table (54 KB) is staged ONCE and the T_SB tiles are consumed one after the other through a
-    // double-buffered entry window; what is needed next (the next tile's window + header words, the next chunk's
-    // table) travels in registers while the current tile is consumed.
-    //
-    // Load discipline (vmcnt counts in issue order and the compiler waits conservatively around branches): in every
-    // step the values loaded one step earlier are consumed FIRST, then the next loads are issued as straight-line,
-    // unconditional instructions (indices are clamped instead of guarded), and the workgroup barrier waits for LDS
-    // traffic only.  So nothing is ever waited for in the step that issued it.
-    __shared__ double s_tab[T_W * T_BL];
-    __shared__ uint2 s_ent[2][T_CAP / 4];
-    const uint32_t tid = threadIdx.x;
-    const uint32_t b0 = blockIdx.x * T_SB, g = blockIdx.y;
+    // A workgroup owns T_SB consecutive 1024-cell blocks and one group of locus chunks.  Per chunk the table is staged
+    // ONCE in LDS and the T_SB tiles are walked one after the other; wave w takes slice w of each tile.  Everything a
+    // step needs was requested two steps earlier: in every step the values loaded before are consumed FIRST, then the
+    // next loads are issued as straight-line, unconditional instructions (indices are clamped instead of guarded).
+    using tab_t = typename std::conditional<EXPECTED, double2, double>::type;
+    constexpr uint32_t TAB_U = T_ROWS * T_BL * sizeof(tab_t) / 16;  // 16-byte units per chunk table
+    constexpr int NP = (TAB_U + T_THREADS - 1) / T_THREADS;         // units per thread (the last one partial)
+    static_assert(NP == 6 || NP == 3, "table prefetch registers are written out by hand");
+    __shared__ tab_t s_tab[T_ROWS * T_BL];
+    __shared__ tab_t s_acc[T_SB * T_BC];  // per-cell sums of the workgroup's blocks
+    const uint32_t tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+    // group = linear block id mod groups: with 8 groups all workgroups of a group land on the same XCD (round-robin
+    // dispatch), whose L2 then serves the group's table reads
+    const uint32_t g = blockIdx.x % groups, col = blockIdx.x / groups;
+    const uint32_t b0 = col * T_SB;
     const uint32_t j0 = g * cpg, j1 = min(nj, j0 + cpg);
-    double ll[T_SB], el[T_SB];
-#pragma unroll
-    for (int s = 0; s < T_SB; s++) ll[s] = el[s] = 0.0;
     if (j0 >= j1) return;
-
-    static_assert(T_NP == 4 && T_CAP / 4 == T_THREADS, "prefetch registers are written out by hand");
-    double2 p_tab0, p_tab1, p_tab2, p_tab3;
-    uint32_t p_rel, p_tot;
-    uint2 p_wb, p_ent;
-    // the fourth table load of a thread may run past the chunk (into the next chunk / the tail pad): never stored
-#define TABLE_PREFETCH(J)                                                                                       \
-    do {                                                                                                        \
-        const double2 *src__ = reinterpret_cast<const double2 *>(tab + (uint64_t)(J) * (T_W * T_BL));           \
-        p_tab0 = src__[tid];                                                                                    \
-        p_tab1 = src__[tid + T_THREADS];                                                                        \
-        p_tab2 = src__[tid + 2 * T_THREADS];                                                                    \
-        p_tab3 = src__[tid + 3 * T_THREADS];                                                                    \
-    } while (0)
-    // block index clamped: a workgroup at the ragged end re-reads the last block and discards the result
-#define TILE_PREFETCH(J, S)                                                                                     \
-    do {                                                                                                        \
-        const uint64_t t__ = (uint64_t)min(b0 + (uint32_t)(S), nb - 1) * nj + (J);                              \
-        const uint64_t o__ = tile_ptr[t__];                                                                     \
-        p_tot = (uint32_t)(tile_ptr[t__ + 1] - o__) - T_HDR; /* entries, padded to a multiple of 8 */           \
-        p_wb = reinterpret_cast<const uint2 *>(tiles + o__)[tid >> 6]; /* wave base, wave total */              \
-        p_rel = (tiles + o__ + 64)[tid];                                                                        \
-        p_ent = reinterpret_cast<const uint2 *>(tiles + o__ + T_HDR)[tid]; /* first window: 4 entries a lane */ \
-    } while (0)
-
-    TABLE_PREFETCH(j0);
-    TILE_PREFETCH(j0, 0);
-    for (uint32_t j = j0; j < j1; j++) {
-        TILE_BARRIER();  // every wave is done with the previous chunk's table
-        {
-            double2 *dst = reinterpret_cast<double2 *>(s_tab);
-            dst[tid] = p_tab0;
-            dst[tid + T_THREADS] = p_tab1;
-            dst[tid + 2 * T_THREADS] = p_tab2;
-            if (tid + 3 * T_THREADS < T_W * T_BL / 2) dst[tid + 3 * T_THREADS] = p_tab3;
-        }
-        const uint32_t jn = min(j + 1, j1 - 1);
+    const uint32_t n_steps = (j1 - j0) * T_SB;
 #pragma unroll
-        for (int s = 0; s < T_SB; s++) {
-            uint2 *win = s_ent[s & 1];
-            // 1. consume what was loaded one step ago
-            uint32_t nxt = (uint32_t)__shfl_down((int)p_rel, 1, 64);  // the next cell's offset = this cell's end
-            if ((tid & 63) == 63) nxt = p_wb.y;
-            const uint32_t my_s = p_wb.x + p_rel, my_e = p_wb.x + nxt, total = p_tot;
-            win[tid] = p_ent;
-            // 2. issue the next step's loads
-            if (s == 0) TABLE_PREFETCH(jn);
-            if (s + 1 < T_SB) TILE_PREFETCH(j, s + 1);
-            else TILE_PREFETCH(jn, 0);
-            TILE_BARRIER();  // window s (and, for s == 0, the table) visible; window s-2 no longer read by anybody
-            // 3. walk this lane's segment
-            const uint16_t *se = reinterpret_cast<const uint16_t *>(win);
-            double a_ll = ll[s], a_el = el[s];
-            for (uint32_t w0 = 0; w0 < total; w0 += T_CAP) {  // total is uniform over the workgroup
-                const uint32_t n_in = min((uint32_t)T_CAP, total - w0);
-                if (w0) {  // a tile larger than one window (dense data): stage the next window synchronously
-                    const uint16_t *tp = tiles + tile_ptr[(uint64_t)min(b0 + (uint32_t)s, nb - 1) * nj + j];
-                    const uint2 *ep = reinterpret_cast<const uint2 *>(tp + T_HDR);
-                    __syncthreads();
-                    win[tid] = ep[(w0 >> 2) + tid];
-                    __syncthreads();
-                }
-                const uint32_t klo = max(my_s, w0), khi = min(my_e, w0 + n_in);
-                for (uint32_t k = klo; k < khi; ++k) {
-                    const uint32_t e = se[k - w0], loc = TE_LOC(e);
-                    a_ll += s_tab[TE_CODE(e) * T_BL + loc];
-                    if (EXPECTED) a_el += s_tab[(TE_NM1(e) + T_NCODE) * T_BL + loc];
-                }
+    for (int s = 0; s < T_SB; s++) {
+        if constexpr (EXPECTED) s_acc[s * T_BC + tid] = make_double2(0.0, 0.0);
+        else s_acc[s * T_BC + tid] = 0.0;
+    }
+
+    // explicit registers (an indexed local array ends up in scratch memory)
+    double2 p_t0, p_t1, p_t2, p_t3, p_t4, p_t5;
+#define TABLE_PREFETCH(J)                                                                                        \
+    do {                                                                                                         \
+        const double2 *src__ = reinterpret_cast<const double2 *>(tab) + (uint64_t)(J) * TAB_U + tid;             \
+        p_t0 = src__[0];                                                                                         \
+        p_t1 = src__[T_THREADS];                                                                                 \
+        p_t2 = src__[2 * T_THREADS]; /* NP == 3: partial, reads into the next chunk / the tail pad */            \
+        if constexpr (NP == 6) {                                                                                 \
+            p_t3 = src__[3 * T_THREADS];                                                                         \
+            p_t4 = src__[4 * T_THREADS];                                                                         \
+            p_t5 = src__[5 * T_THREADS]; /* partial */                                                           \
+        }                                                                                                        \
+    } while (0)
+
+    // Software pipeline over the steps t = (chunk, block) of this workgroup: the rows of step t+2 are requested in step
+    // t; the slice header they need (wave-uniform: scalar loads) is requested in step t-1.  Two buffers serve the even
+    // and the odd steps; a buffer is consumed and then refilled in place.
+    struct row_t { tile_u4 lo, hi; uint32_t k; const uint16_t *ptr; };  // lo: cell + entries 0..6, hi: entries 7..14
+    // slice header of step T (clamped to the last step; a workgroup at the ragged end re-reads the last block)
+    const uint32_t wv_s = (uint32_t)__builtin_amdgcn_readfirstlane((int)wv);
+#define HDR_LOAD(H, T)                                                                                           \
+    do {                                                                                                         \
+        const uint32_t t__ = min((uint32_t)(T), n_steps - 1);                                                    \
+        const uint32_t j__ = j0 + t__ / T_SB, s__ = t__ % T_SB;                                                  \
+        /* The slices of a tile are sorted by length: wave w takes slice w, 15-w, w+8, 7-w (mod 16) of the      */ \
+        /* chunk's tiles, so that all waves carry about the same load between two chunk barriers.               */ \
+        const uint32_t rot__ = (wv_s + 8u * (s__ >> 1)) & 15u, sl__ = (s__ & 1u) ? 15u - rot__ : rot__;          \
+        (H) = reinterpret_cast<const uint4 *>(thdr + ((uint64_t)min(b0 + s__, nb - 1) * nj + j__) * T_HDR)[sl__]; \
+    } while (0)
+    // this lane's row of the slice with header H.  A row of less than 8 u16 is covered by the first load: the second
+    // one then repeats it (never consumed) instead of reading far beyond the row.
+#define ROW_LOAD(E, H)                                                                                           \
+    do {                                                                                                         \
+        (E).k = (H).z;                                                                                           \
+        (E).ptr = tiles + (((uint64_t)(H).y << 32) | (H).x) + lane * ((H).z + 1u);                               \
+        (E).lo = *reinterpret_cast<const tile_u4 *>((E).ptr);                                                    \
+        (E).hi = *reinterpret_cast<const tile_u4 *>((E).ptr + ((H).z > 7u ? 8u : 0u));                           \
+    } while (0)
+
+    uint4 h0, h1;   // at the top of an even step t: slice headers of steps t+2 (h0) and t+3 (h1)
+    row_t e0, e1;   // at the top of an even step t: rows of steps t (e0) and t+1 (e1)
+    // The table loads are the OLDEST requests when the chunk loop is entered, like on its back edge, so that the wait
+    // for them is a counted vmcnt that leaves the younger row requests in flight (the scheduler must not move them
+    // behind the loads below: vmcnt counts in issue order).
+    TABLE_PREFETCH(j0);
+    __builtin_amdgcn_sched_barrier(0);
+    HDR_LOAD(h0, 0);
+    HDR_LOAD(h1, 1);
+    ROW_LOAD(e0, h0);
+    ROW_LOAD(e1, h1);
+    HDR_LOAD(h0, 2);
+    HDR_LOAD(h1, 3);
+    uint32_t t = 0;
+
+    // one step: block S of the current chunk, pipeline buffers E / H
+#if TILE_ABL == 1  /* ablation: no table lookups */
+#define TILE_LOOKUP(V, IDX) do { if constexpr (EXPECTED) V = make_double2((double)(IDX), 1.0); else V = (double)(IDX); } while (0)
+#else
+#define TILE_LOOKUP(V, IDX) V = s_tab[IDX]
+#endif
+    // lookup of entry KK of the row = u16 number KK + 1 = half (KK + 1) & 1 of dword (KK + 1) >> 1.  The slice's K is odd
+    // and wave-uniform, so the lookups come in pairs behind one scalar branch.
+#define TILE_LK(KK)                                                                                              \
+    do {                                                                                                         \
+        const uint32_t idx__ = (((KK) + 1) & 1) ? (w__[((KK) + 1) >> 1] >> 16) : (w__[((KK) + 1) >> 1] & 0xffffu); \
+        tab_t v__;                                                                                               \
+        TILE_LOOKUP(v__, idx__);                                                                                 \
+        if constexpr (EXPECTED) { a_ll__ += v__.x; a_el__ += v__.y; }                                            \
+        else a_ll__ += v__;                                                                                      \
+    } while (0)
+#define TILE_STEP(S, E, H)                                                                                       \
+    do {                                                                                                         \
+        /* 1. consume the row requested two steps ago: u16 number i of the row sits in half i & 1 of dword i >> 1 */ \
+        const uint32_t w__[8] = {(E).lo.x, (E).lo.y, (E).lo.z, (E).lo.w, (E).hi.x, (E).hi.y, (E).hi.z, (E).hi.w}; \
+        const uint32_t K__ = (uint32_t)__builtin_amdgcn_readfirstlane((int)(E).k); /* wave-uniform, odd */       \
+        const uint16_t *cur__ = (E).ptr;                                                                         \
+        const uint32_t cell__ = w__[0] & 0xffffu;                                                                \
+        /* 2. issue the next requests: rows of step t+2 (their header is here), header of step t+4 */            \
+        ROW_LOAD(E, H);                                                                                          \
+        HDR_LOAD(H, t + 4);                                                                                      \
+        /* 3. this lane's cell of the slice: K lookups for every lane (padding entries hit the zero row) */      \
+        double a_ll__ = 0.0, a_el__ = 0.0;                                                                       \
+        /* (written out: a loop with an early exit gets re-rolled and then selects its register at run time) */  \
+        TILE_LK(0);                                                                                              \
+        if (K__ > 1) { TILE_LK(1); TILE_LK(2);                                                                   \
+        if (K__ > 3) { TILE_LK(3); TILE_LK(4);                                                                   \
+        if (K__ > 5) { TILE_LK(5); TILE_LK(6);                                                                   \
+        if (K__ > 7) { TILE_LK(7); TILE_LK(8);                                                                   \
+        if (K__ > 9) { TILE_LK(9); TILE_LK(10);                                                                  \
+        if (K__ > 11) { TILE_LK(11); TILE_LK(12);                                                                \
+        if (K__ > 13) { TILE_LK(13); TILE_LK(14);                                                                \
+        for (uint32_t k = T_NE; k < K__; k++) { /* rare: a slice with more than T_NE entries per cell */         \
+            const tab_t v__ = s_tab[cur__[k + 1]];                                                               \
+            if constexpr (EXPECTED) { a_ll__ += v__.x; a_el__ += v__.y; }                                        \
+            else a_ll__ += v__;                                                                                  \
+        } } } } } } } }                                                                                          \
+        /* 4. add the tile's sums to the cell's accumulator (one lane per cell and tile; tiles of the same     */ \
+        /*    block are separated by the chunk barriers)                                                        */ \
+        {                                                                                                        \
+            tab_t a__ = s_acc[(S) * T_BC + cell__];                                                              \
+            if constexpr (EXPECTED) { a__.x += a_ll__; a__.y += a_el__; }                                        \
+            else a__ += a_ll__;                                                                                  \
+            s_acc[(S) * T_BC + cell__] = a__;                                                                    \
+        }                                                                                                        \
+        t++;                                                                                                     \
+    } while (0)
+
+    static_assert(T_SB == 2 || T_SB == 4, "even and odd steps use different pipeline buffers");
+    for (uint32_t j = j0; j < j1; j++) {
+        TILE_BARRIER();  // every wave is done with the previous chunk's table (and, first time, s_acc is zeroed)
+#if TILE_ABL == 3  /* ablation: table staged for the first chunk only */
+        if (j == j0)
+#endif
+        {
+            double2 *dst = reinterpret_cast<double2 *>(s_tab) + tid;
+            dst[0] = p_t0;
+            dst[T_THREADS] = p_t1;
+            if constexpr (NP == 6) {
+                dst[2 * T_THREADS] = p_t2;
+                dst[3 * T_THREADS] = p_t3;
+                dst[4 * T_THREADS] = p_t4;
+                if (tid + 5 * T_THREADS < TAB_U) dst[5 * T_THREADS] = p_t5;
+            } else {
+                if (tid + 2 * T_THREADS < TAB_U) dst[2 * T_THREADS] = p_t2;
             }
-            ll[s] = a_ll;
-            el[s] = a_el;
+        }
+#if TILE_ABL != 3
+        TABLE_PREFETCH(min(j + 1, j1 - 1));
+#endif
+        TILE_BARRIER();  // table visible
+        TILE_STEP(0, e0, h0);
+        TILE_STEP(1, e1, h1);
+        if constexpr (T_SB == 4) {
+            TILE_STEP(2, e0, h0);
+            TILE_STEP(3, e1, h1);
         }
     }
-#undef TILE_PREFETCH
+#undef TILE_STEP
+#undef TILE_LK
+#undef TILE_LOOKUP
+#undef ROW_LOAD
+#undef HDR_LOAD
 #undef TABLE_PREFETCH
+    TILE_BARRIER();
 #pragma unroll
     for (int s = 0; s < T_SB; s++) {
         if (b0 + s < nb) {
             const uint64_t c = (uint64_t)g * npad + (uint64_t)(b0 + s) * T_BC + tid;
-            part_ll[c] = ll[s];
-            if (EXPECTED) part_ell[c] = el[s];
+            const tab_t a = s_acc[s * T_BC + tid];
+            if constexpr (EXPECTED) { part_ll[c] = a.x; part_ell[c] = a.y; }
+            else part_ll[c] = a;
         }
     }
 }
@@ -453,7 +549,7 @@ __global__ __launch_bounds__(LS_THREADS) void k_locus_stats2(uint64_t L, uint32_
                                                              const uint32_t *__restrict__ c4_ent,
                                                              const uint32_t *__restrict__ flag_bits,
                                                              const uint32_t *__restrict__ hist_all,
-                                                             const double *__restrict__ tab,
+                                                             const double *__restrict__ tab, uint32_t tab_stride,
                                                              const uint8_t *__restrict__ mask,
                                                              const uint64_t *__restrict__ ovc_ptr /*null: no overflow*/,
                                                              const uint64_t *__restrict__ ovc_ent,
@@ -538,7 +634,8 @@ __global__ __launch_bounds__(LS_THREADS) void k_locus_stats2(uint64_t L, uint32_
             amin = mycnt * T_A_OF[lane];
             rmin = mycnt * T_R_OF[lane];
             if (live) {
-                const double t = tab[(l / T_BL) * (uint64_t)(T_W * T_BL) + (uint64_t)lane * T_BL + (l % T_BL)];
+                // this pass' log-pmf table (element stride 2 when it holds (log-pmf, expected) pairs)
+                const double t = tab[((l / T_BL) * TAB_ELEMS + (uint64_t)lane * T_BL + (l % T_BL)) * tab_stride];
                 cmin = (double)mycnt * t;
                 cmaj = (double)(all - mycnt) * t;
             }
@@ -675,61 +772,100 @@ __device__ __forceinline__ uint64_t row_lower_bound(const uint64_t *__restrict__
     return lo;
 }
 
-// one 1024-thread block per tile, thread = cell of the block.  FILL = false: tile size; FILL = true: write the tile.
+// One 1024-thread block per tile, thread = cell of the block.  The cells are ordered by their number of regular entries
+// in this chunk (stable counting sort: deterministic layout), every 64 of them form a slice of 64 rows [cell, K entries]
+// with K = the slice's longest cell rounded up to odd.  FILL = false: tile size; FILL = true: write slices + header.
+#define TB_BINS 64  // entry counts >= TB_BINS-1 share the last bin (they sort to the end, in cell order)
 template <bool FILL>
 __global__ __launch_bounds__(T_BC) void k_tile_build(uint64_t nloc, uint32_t nj, uint64_t tile0,
                                                      const uint64_t *__restrict__ csr_ptr,
                                                      const uint64_t *__restrict__ csr_ent,
                                                      uint64_t *__restrict__ tile_elems /*count pass: out; fill: tile_ptr*/,
-                                                     uint16_t *__restrict__ tiles)
+                                                     uint16_t *__restrict__ tiles, uint16_t *__restrict__ thdr)
 {
-    __shared__ uint32_t s_ws[T_BC / 64];
+    __shared__ uint32_t s_cnt[T_BC / 64][TB_BINS];  // cells per (source wave, bin)
+    __shared__ uint32_t s_base[TB_BINS];            // first rank of a bin
+    __shared__ uint32_t s_kmax[T_BC / 64];          // longest cell of a slice
+    __shared__ uint32_t s_sbase[T_BC / 64 + 1];     // first entry of a slice inside the tile
     const uint64_t t = tile0 + blockIdx.x;
     const uint32_t b = (uint32_t)(t / nj), j = (uint32_t)(t % nj);
     const uint32_t cl = threadIdx.x, lane = cl & 63, wv = cl >> 6;
     const uint64_t row = (uint64_t)b * T_BC + cl;
+    for (uint32_t i = cl; i < (T_BC / 64) * TB_BINS; i += T_BC) (&s_cnt[0][0])[i] = 0;
+    if (cl < T_BC / 64) s_kmax[cl] = 0;
     uint64_t lo = 0, hi = 0;
-    uint32_t reg = 0;
+    uint32_t len = 0;
     if (row < nloc) {
         const uint64_t beg = csr_ptr[row], end = csr_ptr[row + 1];
         lo = row_lower_bound(csr_ent, beg, end, j * T_BL);
         hi = row_lower_bound(csr_ent, lo, end, (j + 1u) * T_BL);
-        for (uint64_t i = lo; i < hi; i++) reg += ent_regular(csr_ent[i]) ? 1u : 0u;
+        for (uint64_t i = lo; i < hi; i++) len += ent_regular(csr_ent[i]) ? 1u : 0u;
     }
-    uint32_t inc = reg;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t o = __shfl_up(inc, off, 64);
-        if (lane >= (uint32_t)off) inc += o;
-    }
-    if (lane == 63) s_ws[wv] = inc;
     __syncthreads();
-    uint32_t woff = 0, total = 0;
-    for (int k = 0; k < T_BC / 64; k++) {
-        const uint32_t v = s_ws[k];
-        if ((uint32_t)k < wv) woff += v;
-        total += v;
+    // stable counting sort by bin = min(len, TB_BINS-1): rank inside (wave, bin) from ballots
+    const uint32_t bin = min(len, (uint32_t)TB_BINS - 1u);
+    uint32_t within = 0;
+    {
+        unsigned long long todo = ~0ull;  // lanes whose bin has not been handled yet
+        while (todo) {
+            const int src = __ffsll((long long)todo) - 1;
+            const uint32_t v = (uint32_t)__shfl((int)bin, src, 64);
+            const unsigned long long m = __ballot(bin == v);
+            if (bin == v) within = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            if ((int)lane == src) s_cnt[wv][v] = (uint32_t)__popcll(m);
+            todo &= ~m;
+        }
     }
+    __syncthreads();
+    if (cl < TB_BINS) {  // exclusive prefix over bins of the bin totals
+        uint32_t tot = 0;
+        for (int w = 0; w < T_BC / 64; w++) tot += s_cnt[w][cl];
+        uint32_t inc = tot;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t o = __shfl_up(inc, off, 64);
+            if ((int)cl >= off) inc += o;
+        }
+        s_base[cl] = inc - tot;
+    }
+    __syncthreads();
+    uint32_t rank = s_base[bin] + within;
+    for (uint32_t w = 0; w < wv; w++) rank += s_cnt[w][bin];
+    const uint32_t dw = rank >> 6, dl = rank & 63;  // destination slice and lane
+    atomicMax(&s_kmax[dw], len);
+    __syncthreads();
+    if (cl == 0) {
+        uint32_t acc = 0;
+        for (int w = 0; w < T_BC / 64; w++) {
+            s_sbase[w] = acc;
+            acc += 64u * ((s_kmax[w] | 1u) + 1u);
+        }
+        s_sbase[T_BC / 64] = acc;
+    }
+    __syncthreads();
     if (!FILL) {
-        if (cl == 0) tile_elems[t] = (uint64_t)T_HDR + ((total + 7u) & ~7u);
+        if (cl == 0) tile_elems[t] = (uint64_t)s_sbase[T_BC / 64];  // a multiple of 128 u16
         return;
     }
-    uint16_t *tp = tiles + tile_elems[t];
-    uint32_t *hd = reinterpret_cast<uint32_t *>(tp);
-    if (lane == 0) {
-        hd[2 * wv] = woff;          // first entry of this wave's cells
-        hd[2 * wv + 1] = s_ws[wv];  // entries of this wave's cells
+    const uint64_t tbase = tile_elems[t];
+    uint16_t *hp = thdr + t * T_HDR;
+    if (cl < T_BC / 64) {
+        uint32_t *hd = reinterpret_cast<uint32_t *>(hp) + 4 * cl;
+        const uint64_t first = tbase + s_sbase[cl];
+        hd[0] = (uint32_t)first;
+        hd[1] = (uint32_t)(first >> 32);
+        hd[2] = s_kmax[cl] | 1u;  // K: padded entries per cell of the slice (odd: a row is K + 1 u16)
+        hd[3] = 0;
     }
-    tp[64 + cl] = (uint16_t)(inc - reg);  // exclusive offset inside the wave: < 64 * T_BL
-    uint16_t *dst = tp + T_HDR + (woff + inc - reg);
+    const uint32_t K = s_kmax[dw] | 1u;
+    uint16_t *dst = tiles + tbase + s_sbase[dw] + dl * (K + 1u);  // this cell's row
+    dst[0] = (uint16_t)cl;
+    uint32_t k = 0;
     for (uint64_t i = lo; i < hi; i++) {
         const uint64_t e = csr_ent[i];
-        if (ent_regular(e))
-            *dst++ = (uint16_t)(((ENT_ALT(e) + ENT_REF(e) - 1u) << 13) | ((ENT_IDX(e) - j * T_BL) << 4) | ent_code(e));
+        if (ent_regular(e)) dst[1 + k++] = (uint16_t)(ent_code(e) * T_BL + (ENT_IDX(e) - j * T_BL));
     }
-    // zero the padding so that staged vectors never carry garbage
-    if (cl == 0)
-        for (uint32_t k = total; k < ((total + 7u) & ~7u); k++) tp[T_HDR + k] = 0;
+    for (; k < K; k++) dst[1 + k] = T_NULL;
 }
 
 // wave per row/column: count entries that are NOT regular (FILL = false) or copy them in order (FILL = true)
@@ -806,7 +942,7 @@ static inline unsigned gcap(uint64_t n, unsigned per_block, unsigned cap = 1u <<
 
 void tiled_free(cellector_ctx *c)
 {
-    dev_free(c->tile_ptr); dev_free(c->tiles); dev_free(c->ovf_ptr); dev_free(c->ovf_ent);
+    dev_free(c->tile_ptr); dev_free(c->tiles); dev_free(c->thdr); dev_free(c->ovf_ptr); dev_free(c->ovf_ent);
     dev_free(c->c4_ptr); dev_free(c->c4_ent); dev_free(c->ovc_ptr); dev_free(c->ovc_ent);
     dev_free(c->hist_all); dev_free(c->tab); dev_free(c->part); dev_free(c->ab3);
     dev_free(c->masked_cnt); dev_free(c->flag_bits); dev_free(c->ovf_perm); dev_free(c->ovf_val); dev_free(c->ovf_tab);
@@ -836,16 +972,18 @@ cellector_status tiled_build(cellector_ctx *c)
     for (uint64_t t0 = 0; t0 < nt; t0 += maxg) {
         const uint64_t g = nt - t0 < maxg ? nt - t0 : maxg;
         hipLaunchKernelGGL(k_tile_build<false>, dim3((unsigned)g), dim3(T_BC), 0, c->stream, nloc, c->t_nj, t0, c->csr_ptr,
-                           c->csr_ent, c->tile_ptr, (uint16_t *)nullptr);
+                           c->csr_ent, c->tile_ptr, (uint16_t *)nullptr, (uint16_t *)nullptr);
     }
     HIPCHK(c, hipGetLastError());
     uint64_t elems = 0;
     CHK(dev_exclusive_scan_u64(c, c->tile_ptr, nt + 1, &elems));
-    CHK(dev_alloc(c, &c->tiles, elems + 2 * T_CAP + 8));  // tail pad: window loads may read past the last tile
+    CHK(dev_alloc(c, &c->tiles, elems + 64));  // tail pad: the 16-byte load of the last row runs past its end
+    CHK(dev_alloc(c, &c->thdr, nt * T_HDR));
+    c->t_elems = elems;
     for (uint64_t t0 = 0; t0 < nt; t0 += maxg) {
         const uint64_t g = nt - t0 < maxg ? nt - t0 : maxg;
         hipLaunchKernelGGL(k_tile_build<true>, dim3((unsigned)g), dim3(T_BC), 0, c->stream, nloc, c->t_nj, t0, c->csr_ptr,
-                           c->csr_ent, c->tile_ptr, c->tiles);
+                           c->csr_ent, c->tile_ptr, c->tiles, c->thdr);
     }
     HIPCHK(c, hipGetLastError());
 
@@ -912,8 +1050,12 @@ cellector_status tiled_build(cellector_ctx *c)
     HIPCHK(c, hipGetLastError());
 
     // ---- per-iteration workspaces
-    const uint64_t tab_elems = (uint64_t)c->t_nj * T_W * T_BL;
-    CHK(dev_alloc(c, &c->tab, 3 * tab_elems + 2 * T_THREADS));  // tail pad for the unconditional fourth table load
+    // tables: three log-pmf-only sets (posterior passes; set 0 also serves an EM pass without the expected column),
+    // then one set of (log-pmf, expected) pairs; tail pad for the unconditional partial last table load
+    const uint64_t tab_elems = (uint64_t)c->t_nj * TAB_ELEMS;
+    CHK(dev_alloc(c, &c->tab, 5 * tab_elems + 4 * T_THREADS));
+    c->tab_em = c->tab;
+    c->tab_em_stride = 1;
     CHK(dev_alloc(c, &c->part, 3ull * 2 * c->t_groups * c->t_npad));
     CHK(dev_alloc(c, &c->ab3, 3 * L));
     CHK(dev_alloc(c, &c->masked_cnt, nloc));
@@ -967,24 +1109,31 @@ static cellector_status side_join(cellector_ctx *c)
 // table build + tile kernel of one pass on the main stream
 static cellector_status run_tile_pass(cellector_ctx *c, const double2 *ab, int set, bool expected)
 {
-    const uint64_t tab_elems = (uint64_t)c->t_nj * T_W * T_BL;
-    double *tab = c->tab + (uint64_t)set * tab_elems;
+    const uint64_t tab_elems = (uint64_t)c->t_nj * TAB_ELEMS;
+    double *tab = expected ? c->tab + 3 * tab_elems : c->tab + (uint64_t)set * tab_elems;
     double *part_ll = c->part + (uint64_t)set * 2 * c->t_groups * c->t_npad;
     double *part_ell = part_ll + (uint64_t)c->t_groups * c->t_npad;
-    hipLaunchKernelGGL(k_build_tables, dim3(gcap((uint64_t)c->t_nj * T_BL, 256)), dim3(256), 0, c->stream, c->L, c->t_nj,
-                       ab, c->lf, tab, expected ? 1 : 0);
+    const unsigned tgrid = gcap((uint64_t)c->t_nj * T_BL, 256);
+    if (expected)
+        hipLaunchKernelGGL(k_build_tables<true>, dim3(tgrid), dim3(256), 0, c->stream, c->L, c->t_nj, ab, c->lf, tab);
+    else
+        hipLaunchKernelGGL(k_build_tables<false>, dim3(tgrid), dim3(256), 0, c->stream, c->L, c->t_nj, ab, c->lf, tab);
+    if (set == 0) {  // the locus pass of this iteration reads the log-pmfs of the EM pass' table
+        c->tab_em = tab;
+        c->tab_em_stride = expected ? 2 : 1;
+    }
     // several cell blocks per workgroup amortise the table staging; with few blocks (small shard) prefer more workgroups
     int sb = T_SB_MAX;
-    while (sb > 1 && (uint64_t)((c->t_nb + sb - 1) / sb) * c->t_groups < 768) sb >>= 1;
-    const dim3 grid((c->t_nb + sb - 1) / sb, c->t_groups);
+    while (sb > 2 && (uint64_t)((c->t_nb + sb - 1) / sb) * c->t_groups < 768) sb >>= 1;
+    const dim3 grid(((c->t_nb + sb - 1) / sb) * c->t_groups);
     timer_begin(c, CELLECTOR_K_TILE_LL);
-#define LAUNCH_TILE(E, S)                                                                                              \
-    hipLaunchKernelGGL((k_tile_ll<E, S>), grid, dim3(T_THREADS), 0, c->stream, c->t_nb, c->t_nj, c->t_cpg, c->tile_ptr, \
+#define LAUNCH_TILE(E, S)                                                                                                  \
+    hipLaunchKernelGGL((k_tile_ll<E, S>), grid, dim3(T_THREADS), 0, c->stream, c->t_nb, c->t_nj, c->t_cpg, c->t_groups, c->thdr, \
                        c->tiles, tab, c->t_npad, part_ll, part_ell)
     if (expected) {
-        if (sb == 4) LAUNCH_TILE(true, 4); else if (sb == 2) LAUNCH_TILE(true, 2); else LAUNCH_TILE(true, 1);
+        if (sb == 4) LAUNCH_TILE(true, 4); else LAUNCH_TILE(true, 2);
     } else {
-        if (sb == 4) LAUNCH_TILE(false, 4); else if (sb == 2) LAUNCH_TILE(false, 2); else LAUNCH_TILE(false, 1);
+        if (sb == 4) LAUNCH_TILE(false, 4); else LAUNCH_TILE(false, 2);
     }
 #undef LAUNCH_TILE
     timer_end(c, CELLECTOR_K_TILE_LL);
@@ -1033,7 +1182,7 @@ cellector_status tiled_locus_pass(cellector_ctx *c)
     if (grid > need) grid = (unsigned)(need ? need : 1);
 #define LAUNCH_LS(INLDS, EBV, GRID, LDSB)                                                                              \
     hipLaunchKernelGGL((k_locus_stats2<INLDS, EBV>), dim3(GRID), dim3(LS_THREADS), LDSB, c->stream, c->L, words, c->c4_ptr, \
-                       c->c4_ent, c->flag_bits, c->hist_all, c->tab, c->mask, c->ovf_n ? c->ovc_ptr : (const uint64_t *)nullptr,  \
+                       c->c4_ent, c->flag_bits, c->hist_all, c->tab_em, (uint32_t)c->tab_em_stride, c->mask, c->ovf_n ? c->ovc_ptr : (const uint64_t *)nullptr,  \
                        c->ovc_ent, c->ovf_val, c->x_locus)
     if (lds <= 128 * 1024) {
         const int lb = (int)(lds ? lds : 4);

@@ -5,6 +5,9 @@ tag=$1; shift
 i=0
 for v in "$@"; do
   out=gpurun_out/$tag/v$i; mkdir -p $out
+  # "lib.so|bench args": run this variant against another build of the library
+  unset CELLECTOR_HIP_LIB
+  case "$v" in *"|"*) export CELLECTOR_HIP_LIB="$PWD/${v%%|*}"; v="${v#*|}";; esac
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 bench.py --no-cpu-baseline $v > $out/bench.json 2> $out/bench.err || { echo "variant $i failed"; tail -5 $out/bench.err; exit 1; }
   python3 - <<PY
 import json,glob,csv
