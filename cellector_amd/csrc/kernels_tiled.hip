@@ -226,8 +226,8 @@ __global__ __launch_bounds__(T_THREADS, 4) void k_tile_ll(uint32_t nb, uint32_t 
             if constexpr (EXPECTED) { a_ll__ += v__.x; a_el__ += v__.y; }                                        \
             else a_ll__ += v__;                                                                                  \
         } } } } } } } }                                                                                          \
-        /* 4. add the tile's sums to the cell's accumulator (one lane per cell and tile; tiles of the same     */ \
-        /*    block are separated by the chunk barriers)                                                        */ \
+        /* 4. add the tile's sums to the cell's accumulator (one lane per cell and tile; tiles of the same block */ \
+        /*    are separated by the chunk barriers).  A read and a write: two ds_add_f64 measured 15 % slower.      */ \
         {                                                                                                        \
             tab_t a__ = s_acc[(S) * T_BC + cell__];                                                              \
             if constexpr (EXPECTED) { a__.x += a_ll__; a__.y += a_el__; }                                        \
