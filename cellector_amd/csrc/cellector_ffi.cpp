@@ -116,7 +116,8 @@ cellector_status cellector_create(cellector_ctx **out, int device_id)
               hipMalloc((void **)&c->d_counters, 8 * sizeof(uint32_t)) == hipSuccess &&
               hipMalloc((void **)&c->sel_hist, SEL_T * 256 * sizeof(uint32_t)) == hipSuccess &&
               hipMalloc((void **)&c->sel_state, 4 * SEL_T * sizeof(uint64_t)) == hipSuccess &&
-              hipHostMalloc((void **)&c->h_sel, 8 * sizeof(uint64_t)) == hipSuccess &&
+              hipMalloc((void **)&c->sel_out, 16 * sizeof(double)) == hipSuccess &&
+              hipHostMalloc((void **)&c->h_sel, 16 * sizeof(double)) == hipSuccess &&
               create_side_stream(&c->side) &&
               hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) == hipSuccess &&
               hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) == hipSuccess;
@@ -135,7 +136,7 @@ void cellector_destroy(cellector_ctx *c)
     if (c->side) (void)hipStreamSynchronize(c->side);
     timer_collect(c);
     free_matrix(c);
-    dev_free(c->lf); dev_free(c->d_counters); dev_free(c->sel_hist); dev_free(c->sel_state);
+    dev_free(c->lf); dev_free(c->d_counters); dev_free(c->sel_hist); dev_free(c->sel_state); dev_free(c->sel_out);
     if (c->h_sel) (void)hipHostFree(c->h_sel);
     if (c->side) (void)hipStreamDestroy(c->side);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
@@ -445,28 +446,10 @@ cellector_status cellector_em_threshold(cellector_ctx *c, double iqr_multiple)
     SETDEV(c);
     const uint64_t n = c->total_cells;
     REQUIRE(c, n > 0, "no cells");
-    // statrs Data::median / quantile: ranks of the order statistics needed
-    const uint64_t k = n / 2;
-    const double h1 = ((double)n + 1.0 / 3.0) * 0.25 + 1.0 / 3.0, h3 = ((double)n + 1.0 / 3.0) * 0.75 + 1.0 / 3.0;
-    const int64_t hf1 = (int64_t)h1, hf3 = (int64_t)h3;
-    auto clampr = [n](int64_t r) -> uint64_t { return r < 0 ? 0 : ((uint64_t)r >= n ? n - 1 : (uint64_t)r); };
-    uint64_t ranks[SEL_T] = {k ? k - 1 : 0, k, clampr(hf1 - 1), clampr(hf1), clampr(hf3 - 1), clampr(hf3)};
-    double v[SEL_T];
-    CHK(select_ranks(c, c->x_norm, n, ranks, v));
-    const double median = (n % 2 != 0) ? v[1] : (v[0] + v[1]) / 2.0;
-    auto quant = [&](double h, int64_t hf, double a, double b, double vmin, double vmax) {
-        if (hf <= 0) return vmin;
-        if (hf >= (int64_t)n) return vmax;
-        return a + (h - (double)hf) * (b - a);
-    };
-    // hf <= 0 / hf >= n only for n <= 2; the clamped ranks then already are min / max
-    const double q1 = quant(h1, hf1, v[2], v[3], v[3], v[2]);
-    const double q3 = quant(h3, hf3, v[4], v[5], v[5], v[4]);
-    const double iqr = q3 - q1;
-    const double thr = q1 - iqr_multiple * iqr;  // main.rs:328-329
-    c->last_median = median; c->last_iqr = iqr; c->last_thr = thr;
+    // exact median / R-8 quartiles / threshold, all on the device (no host round trip in this phase)
+    CHK(select_threshold(c, c->x_norm, n, iqr_multiple));
     HIPCHK(c, hipMemsetAsync(c->x_locus + (uint64_t)LB_PLANES * c->L, 0, LC_COUNTERS * 8, c->stream));
-    CHK(launch_flag(c, thr));
+    CHK(launch_flag(c, c->sel_out + 10));
     if (c->engine == 2) CHK(tiled_locus_pass(c));
     else CHK(launch_locus_stats(c));
     c->em_phase = 2;
@@ -485,7 +468,9 @@ cellector_status cellector_em_finish(cellector_ctx *c, cellector_iter_summary *o
     uint32_t dc[8];
     HIPCHK(c, hipMemcpyAsync(cnt, c->x_locus + (uint64_t)LB_PLANES * c->L, sizeof cnt, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(dc, c->d_counters, sizeof dc, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->h_sel, c->sel_out + 8, 3 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));  // the iteration's only host synchronisation
+    c->last_median = c->h_sel[0]; c->last_iqr = c->h_sel[1]; c->last_thr = c->h_sel[2];
     if (dc[0]) {
         c->n_masked_loci += dc[0];
         if (c->tiled_ready) CHK(tiled_masked_update(c));

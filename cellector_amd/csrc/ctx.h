@@ -40,7 +40,7 @@ struct cellector_ctx {
     // side stream for the small overflow kernels that run next to the tile kernel (fork/join with events)
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    int overlap = 0;  // option "overlap": 1 = overflow kernels on the (low-priority) side stream
+    int overlap = 1;  // option "overlap": 1 = overflow kernels on the (low-priority) side stream next to the tile kernel
     mutable std::string err;
 
     // options
@@ -119,8 +119,9 @@ struct cellector_ctx {
 
     // order-statistic workspace
     uint32_t *sel_hist = nullptr;   // [SEL_T][256]
-    uint64_t *sel_state = nullptr;  // [SEL_T][2] prefix, remaining rank
-    uint64_t *h_sel = nullptr;      // pinned [SEL_T]
+    uint64_t *sel_state = nullptr;  // [SEL_T][2] prefix, remaining rank; then the ticket counter
+    double *sel_out = nullptr;      // [16] device: [0..5] order statistics, [8..10] median, iqr, threshold
+    double *h_sel = nullptr;        // pinned [16]: iteration summary read back in em_finish
 
     // iteration bookkeeping
     uint64_t iteration = 0;
@@ -175,7 +176,7 @@ void timer_collect(cellector_ctx *c);
 // EM loop
 cellector_status launch_alpha_beta(cellector_ctx *c);
 cellector_status launch_cell_ll(cellector_ctx *c, const double2 *ab, double *norm_out /*may be null*/);
-cellector_status launch_flag(cellector_ctx *c, double thr);
+cellector_status launch_flag(cellector_ctx *c, const double *d_thr);
 cellector_status launch_locus_stats(cellector_ctx *c);
 cellector_status launch_locus_filter(cellector_ctx *c);
 cellector_status launch_ab_from_host(cellector_ctx *c, const double *alpha, const double *beta,
@@ -184,8 +185,8 @@ cellector_status launch_posteriors(cellector_ctx *c, double mf0, double lp_min, 
                                    double lp_dbl);
 cellector_status launch_final_tallies(cellector_ctx *c, uint64_t *d_out /*[4*total_loci]*/);
 // order statistics: exact values at SEL_T 0-based ranks of n keys
-cellector_status select_ranks(cellector_ctx *c, const double *keys, uint64_t n,
-                              const uint64_t ranks[SEL_T], double out[SEL_T]);
+cellector_status select_ranks(cellector_ctx *c, const double *keys, uint64_t n, const uint64_t ranks[SEL_T]);
+cellector_status select_threshold(cellector_ctx *c, const double *keys, uint64_t n, double iqr_multiple);
 // ingest
 cellector_status ingest_stage_host_coo(cellector_ctx *c, uint64_t nnz, const uint32_t *locus0,
                                        const uint32_t *cell0, const uint32_t *alt, const uint32_t *ref);

@@ -86,10 +86,11 @@ __global__ __launch_bounds__(BLOCK) void k_cell_ll(uint64_t n_rows, const uint64
 // new_excluded = {i : norm_i < threshold} (main.rs:330-332) and the symmetric-difference counts
 // (main.rs:333-334) accumulated as f64 into the LOCUS exchange buffer's counter slots.
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_flag(uint64_t n, const double *__restrict__ norm, double thr,
+__global__ __launch_bounds__(256) void k_flag(uint64_t n, const double *__restrict__ norm, const double *__restrict__ d_thr,
                                               const uint8_t *__restrict__ old_flags, uint8_t *__restrict__ new_flags,
                                               double *__restrict__ counters)
 {
+    const double thr = *d_thr;  // computed on the device by k_threshold
     uint32_t c_new = 0, c_res = 0, c_exc = 0;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
         const bool nf = norm[i] < thr;
@@ -320,11 +321,11 @@ cellector_status launch_cell_ll(cellector_ctx *c, const double2 *ab, double *nor
     return CELLECTOR_OK;
 }
 
-cellector_status launch_flag(cellector_ctx *c, double thr)
+cellector_status launch_flag(cellector_ctx *c, const double *d_thr)
 {
     if (c->nloc == 0) return CELLECTOR_OK;
     hipLaunchKernelGGL(k_flag, dim3(grid_for(c->nloc, 256 * 16, 1024)), dim3(256), 0, c->stream, c->nloc,
-                       c->x_norm + c->cell_begin, thr, c->flags, c->flags_new, c->x_locus + LB_PLANES * c->L);
+                       c->x_norm + c->cell_begin, d_thr, c->flags, c->flags_new, c->x_locus + LB_PLANES * c->L);
     HIPCHK(c, hipGetLastError());
     return CELLECTOR_OK;
 }

@@ -1,11 +1,12 @@
 // Exact order statistics of N f64 keys on the device (statrs Data::median / Data::quantile need the
 // values at up to six ranks: main.rs:324-327).
 //
-// MSB-first radix select, 8 bits per pass, all SEL_T target ranks refined together: per pass one
-// histogram kernel (keys that match a target's resolved prefix vote into that target's 256-bin LDS
-// histogram; votes are aggregated per wave before the LDS atomic, then per block before the global
-// atomic) and one single-wave kernel that walks each histogram to the bin holding the target rank.
-// Targets that still share a prefix share one histogram (the first of the group computes, the rest copy).
+// MSB-first radix select, 8 bits per pass, all SEL_T target ranks refined together: per pass one histogram
+// kernel (keys that match a target's resolved prefix vote into that target's 256-bin LDS histogram; votes are
+// aggregated per wave before the LDS atomic, then per block before the global atomic) and one single-wave
+// kernel that walks each histogram to the bin holding the target rank.  Targets that still share a prefix share one
+// histogram.  The results stay in device memory: the threshold arithmetic and the flagging kernel read them
+// there, so the phase needs no host round trip.
 #include "ctx.h"
 
 #define SEL_BLOCK 256
@@ -23,18 +24,78 @@ __device__ __forceinline__ double value_of(uint64_t k)
 }
 
 // state[t] = {prefix (resolved high bits, low bits zero), remaining rank inside that prefix}
-__global__ void k_sel_init(const uint64_t *__restrict__ ranks, uint64_t *__restrict__ state)
+struct sel_ranks_t { uint64_t r[SEL_T]; };
+
+__global__ void k_sel_init(sel_ranks_t ranks, uint64_t *__restrict__ state, uint32_t *__restrict__ hist)
 {
-    int t = threadIdx.x;
+    const int t = threadIdx.x;
     if (t < SEL_T) {
         state[2 * t] = 0;
-        state[2 * t + 1] = ranks[t];
+        state[2 * t + 1] = ranks.r[t];
     }
+    for (int i = t; i < SEL_T * 256; i += blockDim.x) hist[i] = 0;
 }
 
-__global__ __launch_bounds__(SEL_BLOCK) void k_sel_hist(const double *__restrict__ keys, uint64_t n, int pass,
-                                                        const uint64_t *__restrict__ state,
-                                                        uint32_t *__restrict__ hist)
+// one wave: for each target find the bin of its (leader's) histogram that holds the remaining rank.
+// Lane i owns bins 4i..4i+3; a shuffle scan over the lane sums locates the lane, then the bin inside it.
+__device__ __forceinline__ void sel_step(int lane, int pass, uint64_t *__restrict__ state, uint32_t *__restrict__ hist,
+                                         double *__restrict__ out)
+{
+    uint64_t prefix[SEL_T], rank[SEL_T], newp[SEL_T], newr[SEL_T];
+#pragma unroll
+    for (int t = 0; t < SEL_T; t++) {
+        prefix[t] = state[2 * t];
+        rank[t] = state[2 * t + 1];
+    }
+    const int shift = 56 - 8 * pass;
+#pragma unroll
+    for (int t = 0; t < SEL_T; t++) {
+        int ld = t;
+#pragma unroll
+        for (int u = SEL_T - 1; u >= 0; u--)
+            if (u < t && prefix[u] == prefix[t]) ld = u;
+        const uint4 h4 = reinterpret_cast<const uint4 *>(hist + ld * 256)[lane];
+        const uint32_t hs[4] = {h4.x, h4.y, h4.z, h4.w};
+        const uint32_t lsum = hs[0] + hs[1] + hs[2] + hs[3];
+        uint32_t inc = lsum;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t o = __shfl_up(inc, off, 64);
+            if (lane >= off) inc += o;
+        }
+        const uint64_t exc = inc - lsum;
+        // the lane whose bins contain the rank (the last lane if counts are short: defensive, cannot happen)
+        const bool mine = (exc <= rank[t] && rank[t] < (uint64_t)inc) || (lane == 63 && rank[t] >= (uint64_t)inc);
+        uint32_t d = 0;
+        uint64_t cum = exc;
+        if (mine) {
+            d = 4 * lane;
+#pragma unroll
+            for (int q = 0; q < 3; q++) {
+                if (cum + hs[q] <= rank[t] && d == (uint32_t)(4 * lane + q)) { cum += hs[q]; d++; }
+            }
+        }
+        const unsigned long long who = __ballot(mine);
+        const int src = __ffsll((long long)who) - 1;
+        const uint32_t dsel = (uint32_t)__shfl((int)d, src, 64);
+        const uint64_t cumsel = (uint64_t)__shfl((long long)cum, src, 64);
+        newp[t] = prefix[t] | ((uint64_t)dsel << shift);
+        newr[t] = rank[t] - cumsel;
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int t = 0; t < SEL_T; t++) {
+            state[2 * t] = newp[t];
+            state[2 * t + 1] = newr[t];
+            if (pass == SEL_PASSES - 1) out[t] = value_of(newp[t]);
+        }
+    }
+    for (int i = lane; i < SEL_T * 256; i += 64) hist[i] = 0;  // ready for the next pass
+}
+
+// histogram of one digit of the keys that match a target's resolved prefix
+__global__ __launch_bounds__(SEL_BLOCK) void k_sel_pass(const double *__restrict__ keys, uint64_t n, int pass,
+                                                        const uint64_t *__restrict__ state, uint32_t *__restrict__ hist)
 {
     __shared__ uint32_t h[SEL_T][256];
     __shared__ uint64_t prefix[SEL_T];
@@ -73,100 +134,73 @@ __global__ __launch_bounds__(SEL_BLOCK) void k_sel_hist(const double *__restrict
     __syncthreads();
     for (int i = threadIdx.x; i < SEL_T * 256; i += SEL_BLOCK) {
         const uint32_t v = (&h[0][0])[i];
-        if (v) atomicAdd(&hist[i], v);
+        if (v) atomicAdd(&hist[i], v);  // agent scope
     }
 }
 
-// one wave: for each target find the bin of its (leader's) histogram that holds the remaining rank.
-// Lane i owns bins 4i..4i+3; a shuffle scan over the lane sums locates the lane, then the bin inside it.
-__global__ void k_sel_step(int pass, uint64_t *__restrict__ state, uint32_t *__restrict__ hist)
+// one wave: the selection step of a pass.  (Fusing it into k_sel_pass behind a last-workgroup ticket measured slower:
+// 25 us per pass against 13 + 5 us for the two launches.)
+__global__ void k_sel_step(int pass, uint64_t *__restrict__ state, uint32_t *__restrict__ hist, double *__restrict__ out)
 {
-    const int lane = threadIdx.x;
-    uint64_t prefix[SEL_T], rank[SEL_T], newp[SEL_T], newr[SEL_T];
-#pragma unroll
-    for (int t = 0; t < SEL_T; t++) {
-        prefix[t] = state[2 * t];
-        rank[t] = state[2 * t + 1];
-    }
-    const int shift = 56 - 8 * pass;
-#pragma unroll
-    for (int t = 0; t < SEL_T; t++) {
-        int ld = t;
-#pragma unroll
-        for (int u = SEL_T - 1; u >= 0; u--)
-            if (u < t && prefix[u] == prefix[t]) ld = u;
-        const uint4 h = reinterpret_cast<const uint4 *>(hist + ld * 256)[lane];
-        const uint32_t lsum = h.x + h.y + h.z + h.w;
-        uint32_t inc = lsum;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const uint32_t o = __shfl_up(inc, off, 64);
-            if (lane >= off) inc += o;
-        }
-        const uint64_t exc = inc - lsum;
-        // the lane whose bins contain the rank (the last lane if counts are short: defensive, cannot happen)
-        const bool mine = (exc <= rank[t] && rank[t] < (uint64_t)inc) || (lane == 63 && rank[t] >= (uint64_t)inc);
-        uint32_t d = 0;
-        uint64_t cum = exc;
-        if (mine) {
-            const uint32_t hs[4] = {h.x, h.y, h.z, h.w};
-            d = 4 * lane;
-#pragma unroll
-            for (int q = 0; q < 3; q++) {
-                if (cum + hs[q] <= rank[t] && d == (uint32_t)(4 * lane + q)) { cum += hs[q]; d++; }
-            }
-        }
-        const unsigned long long who = __ballot(mine);
-        const int src = __ffsll((long long)who) - 1;
-        const uint32_t dsel = (uint32_t)__shfl((int)d, src, 64);
-        const uint64_t cumsel = (uint64_t)__shfl((long long)cum, src, 64);
-        newp[t] = prefix[t] | ((uint64_t)dsel << shift);
-        newr[t] = rank[t] - cumsel;
-    }
-    __syncthreads();
-    if (lane == 0) {
-#pragma unroll
-        for (int t = 0; t < SEL_T; t++) {
-            state[2 * t] = newp[t];
-            state[2 * t + 1] = newr[t];
-        }
-    }
-    for (int i = lane; i < SEL_T * 256; i += 64) hist[i] = 0;  // ready for the next pass
+    sel_step((int)threadIdx.x, pass, state, hist, out);
 }
 
-__global__ void k_sel_finish(const uint64_t *__restrict__ state, double *__restrict__ out)
+// statrs Data::median / quantile and the threshold of main.rs:328-329 from the six order statistics,
+// in the reference's operation order: out = {median, iqr, threshold}
+struct sel_quart_t { double h1, h3; int64_t hf1, hf3; uint64_t n; double iqr_multiple; };
+__global__ void k_threshold(sel_quart_t q, const double *__restrict__ v, double *__restrict__ out)
 {
-    int t = threadIdx.x;
-    if (t < SEL_T) out[t] = value_of(state[2 * t]);
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const double median = (q.n % 2 != 0) ? v[1] : (v[0] + v[1]) / 2.0;
+    // hf <= 0 / hf >= n only for n <= 2; the clamped ranks then already are min / max
+    double q1, q3;
+    if (q.hf1 <= 0) q1 = v[3]; else if (q.hf1 >= (int64_t)q.n) q1 = v[2]; else q1 = v[2] + (q.h1 - (double)q.hf1) * (v[3] - v[2]);
+    if (q.hf3 <= 0) q3 = v[5]; else if (q.hf3 >= (int64_t)q.n) q3 = v[4]; else q3 = v[4] + (q.h3 - (double)q.hf3) * (v[5] - v[4]);
+    const double iqr = q3 - q1;
+    out[0] = median;
+    out[1] = iqr;
+    out[2] = q1 - q.iqr_multiple * iqr;  // main.rs:328-329
 }
 
-cellector_status select_ranks(cellector_ctx *c, const double *keys, uint64_t n, const uint64_t ranks[SEL_T],
-                              double out[SEL_T])
+// exact values at SEL_T 0-based ranks of n keys, left in device memory (c->sel_out); no host synchronisation
+cellector_status select_ranks(cellector_ctx *c, const double *keys, uint64_t n, const uint64_t ranks[SEL_T])
 {
     if (n == 0) return ctx_fail(c, CELLECTOR_EINVAL, "order statistics of an empty array");
-    for (int t = 0; t < SEL_T; t++)
+    sel_ranks_t r;
+    for (int t = 0; t < SEL_T; t++) {
         if (ranks[t] >= n) return ctx_fail(c, CELLECTOR_EINVAL, "rank %llu out of range", (unsigned long long)ranks[t]);
+        r.r[t] = ranks[t];
+    }
     timer_begin(c, CELLECTOR_K_SELECT);
-    // h_sel is pinned: ranks in, values out
-    for (int t = 0; t < SEL_T; t++) c->h_sel[t] = ranks[t];
-    uint64_t *d_ranks = c->sel_state + 2 * SEL_T;  // scratch tail of the state buffer
-    HIPCHK(c, hipMemcpyAsync(d_ranks, c->h_sel, SEL_T * 8, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemsetAsync(c->sel_hist, 0, SEL_T * 256 * 4, c->stream));
-    hipLaunchKernelGGL(k_sel_init, dim3(1), dim3(64), 0, c->stream, d_ranks, c->sel_state);
+    hipLaunchKernelGGL(k_sel_init, dim3(1), dim3(256), 0, c->stream, r, c->sel_state, c->sel_hist);
     uint64_t g = (n + SEL_BLOCK * 8 - 1) / (SEL_BLOCK * 8);
     if (g > 1024) g = 1024;
     if (g < 1) g = 1;
     for (int pass = 0; pass < SEL_PASSES; pass++) {
-        hipLaunchKernelGGL(k_sel_hist, dim3((unsigned)g), dim3(SEL_BLOCK), 0, c->stream, keys, n, pass, c->sel_state,
-                           c->sel_hist);
-        hipLaunchKernelGGL(k_sel_step, dim3(1), dim3(64), 0, c->stream, pass, c->sel_state, c->sel_hist);
+        hipLaunchKernelGGL(k_sel_pass, dim3((unsigned)g), dim3(SEL_BLOCK), 0, c->stream, keys, n, pass, c->sel_state, c->sel_hist);
+        hipLaunchKernelGGL(k_sel_step, dim3(1), dim3(64), 0, c->stream, pass, c->sel_state, c->sel_hist, c->sel_out);
     }
-    double *d_out = reinterpret_cast<double *>(d_ranks);
-    hipLaunchKernelGGL(k_sel_finish, dim3(1), dim3(64), 0, c->stream, c->sel_state, d_out);
     timer_end(c, CELLECTOR_K_SELECT);
     HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipMemcpyAsync(c->h_sel, d_out, SEL_T * 8, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    for (int t = 0; t < SEL_T; t++) memcpy(&out[t], &c->h_sel[t], 8);
+    return CELLECTOR_OK;
+}
+
+// median / quartiles / threshold of n keys into c->sel_out[8..10] = {median, iqr, threshold} (device memory)
+cellector_status select_threshold(cellector_ctx *c, const double *keys, uint64_t n, double iqr_multiple)
+{
+    // statrs Data::median / quantile: ranks of the order statistics needed
+    const uint64_t k = n / 2;
+    sel_quart_t q;
+    q.h1 = ((double)n + 1.0 / 3.0) * 0.25 + 1.0 / 3.0;
+    q.h3 = ((double)n + 1.0 / 3.0) * 0.75 + 1.0 / 3.0;
+    q.hf1 = (int64_t)q.h1;
+    q.hf3 = (int64_t)q.h3;
+    q.n = n;
+    q.iqr_multiple = iqr_multiple;
+    auto clampr = [n](int64_t r) -> uint64_t { return r < 0 ? 0 : ((uint64_t)r >= n ? n - 1 : (uint64_t)r); };
+    const uint64_t ranks[SEL_T] = {k ? k - 1 : 0, k, clampr(q.hf1 - 1), clampr(q.hf1), clampr(q.hf3 - 1), clampr(q.hf3)};
+    CHK(select_ranks(c, keys, n, ranks));
+    hipLaunchKernelGGL(k_threshold, dim3(1), dim3(64), 0, c->stream, q, c->sel_out, c->sel_out + 8);
+    HIPCHK(c, hipGetLastError());
     return CELLECTOR_OK;
 }

@@ -567,17 +567,37 @@ __global__ __launch_bounds__(LS_THREADS) void k_locus_stats2(uint64_t L, uint32_
     const int lane = threadIdx.x & 63;
     const uint64_t wave0 = (uint64_t)blockIdx.x * (LS_THREADS / 64) + (threadIdx.x >> 6);
     const uint64_t nwaves = (uint64_t)gridDim.x * (LS_THREADS / 64);
+    // the column pointers of a locus are requested one locus ahead, its per-code constants at the top of its turn: a
+    // short column (a small shard) then costs one memory latency, not three in a row
+    uint64_t n_c4b = 0, n_c4e = 0, n_ob = 0, n_oe = 0;
+    if (wave0 < L) {
+        n_c4b = c4_ptr[wave0]; n_c4e = c4_ptr[wave0 + 1];
+        if (ovc_ptr) { n_ob = ovc_ptr[wave0]; n_oe = ovc_ptr[wave0 + 1]; }
+    }
     for (uint64_t l = wave0; l < L; l += nwaves) {
         // columns are padded to groups of four entries (code 15 = no entry): 16 bytes at 32 bits, 12 bytes at 24 bits
-        const uint64_t vbeg = c4_ptr[l] >> 2, nvec = (c4_ptr[l + 1] >> 2) - vbeg;
+        const uint64_t vbeg = n_c4b >> 2, nvec = (n_c4e >> 2) - vbeg;
         const uint32_t *wp = c4_ent + vbeg * (EB == 32 ? 4 : 3);
+        const uint64_t obeg = n_ob, oend = n_oe;
+        {
+            const uint64_t ln = min(l + nwaves, L - 1);  // clamped: the last round re-reads a valid locus
+            n_c4b = c4_ptr[ln]; n_c4e = c4_ptr[ln + 1];
+            if (ovc_ptr) { n_ob = ovc_ptr[ln]; n_oe = ovc_ptr[ln + 1]; }
+        }
+        // per-code constants of this locus (lanes 0..13): static histogram, this pass' log-pmf, the loci mask
+        const bool live = mask[l] != 0;
+        uint32_t h_all = 0;
+        double t_code = 0.0;
+        if (lane < T_NCODE) {
+            h_all = hist_all[l * T_NCODE + lane];
+            // (element stride 2 when the table holds (log-pmf, expected) pairs)
+            t_code = tab[((l / T_BL) * TAB_ELEMS + (uint64_t)lane * T_BL + (l % T_BL)) * tab_stride];
+        }
         // this locus' overflow entries (alt+ref == 0 or > T_K; ~1 %): their stored log-pmfs are only gathered.  The
-        // first 64 are requested now and consumed after the column has been streamed.
-        uint64_t obeg = 0, oend = 0, o_en = 0, o_en2 = 0;
+        // first 128 are requested now and consumed after the column has been streamed.
+        uint64_t o_en = 0, o_en2 = 0;
         double o_lp = 0.0, o_lp2 = 0.0;
         if (ovc_ptr) {
-            obeg = ovc_ptr[l];
-            oend = ovc_ptr[l + 1];
             if (obeg + lane < oend) {
                 o_en = ovc_ent[obeg + lane];
                 o_lp = ovf_val[obeg + lane].x;
@@ -625,22 +645,18 @@ __global__ __launch_bounds__(LS_THREADS) void k_locus_stats2(uint64_t L, uint32_
             mycnt = whist[lane];
             whist[lane] = 0;
         }
-        const bool live = mask[l] != 0;
         double cmin = 0.0, cmaj = 0.0;
         uint32_t nmin = 0, amin = 0, rmin = 0;
         if (lane < T_NCODE) {
-            const uint32_t all = hist_all[l * T_NCODE + lane];
             nmin = mycnt;
             amin = mycnt * T_A_OF[lane];
             rmin = mycnt * T_R_OF[lane];
             if (live) {
-                // this pass' log-pmf table (element stride 2 when it holds (log-pmf, expected) pairs)
-                const double t = tab[((l / T_BL) * TAB_ELEMS + (uint64_t)lane * T_BL + (l % T_BL)) * tab_stride];
-                cmin = (double)mycnt * t;
-                cmaj = (double)(all - mycnt) * t;
+                cmin = (double)mycnt * t_code;
+                cmaj = (double)(h_all - mycnt) * t_code;
             }
         }
-        // fixed-shape sum over the nine codes (lanes 0..8): deterministic
+        // fixed-shape sum over the codes (lanes 0..13): deterministic
         cmin = wave_sum(cmin);
         cmaj = wave_sum(cmaj);
         nmin = wave_sum_u32(nmin);
@@ -959,7 +975,18 @@ cellector_status tiled_build(cellector_ctx *c)
     c->t_nj = (uint32_t)((L + T_BL - 1) / T_BL);
     if (c->t_nb == 0) c->t_nb = 1;
     if (c->t_nj == 0) c->t_nj = 1;
-    c->t_groups = c->t_nj < T_GROUPS ? c->t_nj : T_GROUPS;
+    // Chunk groups: a multiple of the 8 XCDs (workgroup i runs on XCD i mod 8, so a group's workgroups share one L2),
+    // more of them when the shard has few cell blocks, so that the tile kernel still launches several rounds of
+    // workgroups per CU (one workgroup per CU at a time) — at the price of one more partial sum per cell and group.
+    {
+        int ncu = 256;
+        (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, c->device);
+        const uint64_t cols = (c->t_nb + T_SB_MAX - 1) / T_SB_MAX, want = 4ull * (uint64_t)ncu;
+        uint64_t groups = T_GROUPS * ((want + cols * T_GROUPS - 1) / (cols * T_GROUPS));
+        if (groups > 64) groups = 64;
+        if (groups > c->t_nj) groups = c->t_nj;
+        c->t_groups = (uint32_t)groups;
+    }
     c->t_cpg = (c->t_nj + c->t_groups - 1) / c->t_groups;
     c->t_groups = (c->t_nj + c->t_cpg - 1) / c->t_cpg;
     c->t_npad = (uint64_t)c->t_nb * T_BC;
@@ -1124,7 +1151,7 @@ static cellector_status run_tile_pass(cellector_ctx *c, const double2 *ab, int s
     }
     // several cell blocks per workgroup amortise the table staging; with few blocks (small shard) prefer more workgroups
     int sb = T_SB_MAX;
-    while (sb > 2 && (uint64_t)((c->t_nb + sb - 1) / sb) * c->t_groups < 768) sb >>= 1;
+    while (sb > 2 && (uint64_t)((c->t_nb + sb - 1) / sb) * c->t_groups < 512) sb >>= 1;
     const dim3 grid(((c->t_nb + sb - 1) / sb) * c->t_groups);
     timer_begin(c, CELLECTOR_K_TILE_LL);
 #define LAUNCH_TILE(E, S)                                                                                                  \
@@ -1146,12 +1173,17 @@ cellector_status tiled_cell_pass(cellector_ctx *c, const double2 *ab, double *no
     if (c->nloc == 0) return CELLECTOR_OK;
     timer_begin(c, CELLECTOR_K_CELL_LL);
     const bool ovf = have_overflow(c);
-    if (ovf) {
-        if (c->overlap) CHK(side_fork(c));
-        launch_overflow_pass(c, c->overlap ? c->side : c->stream, ab, 0, c->compute_expected);
+    if (ovf && c->overlap) {
+        // the side stream may start now, but its kernels are submitted AFTER the tile kernel: they fill the wave slots
+        // the tile workgroups (one per CU, 16 of its 32 wave slots) leave free instead of taking CUs away from them
+        CHK(side_fork(c));
+        CHK(run_tile_pass(c, ab, 0, c->compute_expected));
+        launch_overflow_pass(c, c->side, ab, 0, c->compute_expected);
+        CHK(side_join(c));
+    } else {
+        if (ovf) launch_overflow_pass(c, c->stream, ab, 0, c->compute_expected);
+        CHK(run_tile_pass(c, ab, 0, c->compute_expected));
     }
-    CHK(run_tile_pass(c, ab, 0, c->compute_expected));
-    if (ovf && c->overlap) CHK(side_join(c));
     double *part_ll = c->part, *part_ell = c->part + (uint64_t)c->t_groups * c->t_npad;
     const double *o_ll = ovf ? c->ovf_sum : nullptr, *o_ell = ovf ? c->ovf_sum + c->nloc : nullptr;
     const unsigned grid = gcap(c->nloc, 256, 0x7fffffffu);
@@ -1226,13 +1258,16 @@ cellector_status tiled_posteriors(cellector_ctx *c, double mf0, double lp_min, d
     if (c->nloc == 0) return CELLECTOR_OK;
     timer_begin(c, CELLECTOR_K_POSTERIOR);
     const bool ovf = have_overflow(c);
-    if (ovf) {
-        if (c->overlap) CHK(side_fork(c));
-        for (int set = 0; set < 3; set++)
-            launch_overflow_pass(c, c->overlap ? c->side : c->stream, c->ab3 + (uint64_t)set * L, set, false);
+    if (ovf && c->overlap) {
+        CHK(side_fork(c));
+        for (int set = 0; set < 3; set++) CHK(run_tile_pass(c, c->ab3 + (uint64_t)set * L, set, false));
+        for (int set = 0; set < 3; set++) launch_overflow_pass(c, c->side, c->ab3 + (uint64_t)set * L, set, false);
+        CHK(side_join(c));
+    } else {
+        if (ovf)
+            for (int set = 0; set < 3; set++) launch_overflow_pass(c, c->stream, c->ab3 + (uint64_t)set * L, set, false);
+        for (int set = 0; set < 3; set++) CHK(run_tile_pass(c, c->ab3 + (uint64_t)set * L, set, false));
     }
-    for (int set = 0; set < 3; set++) CHK(run_tile_pass(c, c->ab3 + (uint64_t)set * L, set, false));
-    if (ovf && c->overlap) CHK(side_join(c));
     hipLaunchKernelGGL(k_posterior_finalize, dim3(gcap(c->nloc, 256, 0x7fffffffu)), dim3(256), 0, c->stream, c->nloc,
                        ovf ? c->ovf_sum : (const double *)nullptr, c->t_groups, c->t_npad, c->part, lp_min, lp_maj, lp_dbl, c->post);
     timer_end(c, CELLECTOR_K_POSTERIOR);
