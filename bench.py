@@ -241,6 +241,7 @@ def main():
         rp, ent = g.csr_rows(0, n_sample)
         lc = g.locus_counts()
         o = ob.Oracle.from_csr(L, rp, ent, lc)
+        ob.set_threads(1)
         t1 = time.perf_counter()
         o.em_iteration(5.0)
         cpu_s = time.perf_counter() - t1
@@ -251,6 +252,17 @@ def main():
             "host_cpus": os.cpu_count(),
         }
         out["gpu_over_cpu_1core"] = out["value"] / out["cpu_baseline"]["value"]
+        # the reference is single-threaded; the same port with its per-cell loop on all host cores, for scale
+        nt = ob.host_threads(cap=256)
+        if nt > 1:
+            ob.set_threads(nt)
+            o.em_iteration(5.0)  # spin up the pool
+            t1 = time.perf_counter()
+            o.em_iteration(5.0)
+            cpu_mt = time.perf_counter() - t1
+            ob.set_threads(1)
+            out["cpu_baseline_all_cores"] = {"value": float(len(ent)) / cpu_mt, "unit": "evals/s", "cores": nt, "kind": "port",
+                                             "sample": f"same sample, per-cell loop on {nt} threads (OpenMP), {cpu_mt:.2f} s"}
         o.close()
     elif rank == 0:
         out["cpu_baseline"] = None
