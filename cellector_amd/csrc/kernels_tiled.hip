@@ -540,6 +540,7 @@ __global__ void k_pack_flag_bits(uint64_t n, const uint8_t *__restrict__ flags, 
     if ((threadIdx.x & 31) == 0 && w * 32 < n) bits[w] = (uint32_t)(m >> (threadIdx.x & 32));
 }
 
+struct __attribute__((packed, aligned(4))) ls_u3 { uint32_t x, y, z; };  // 12-byte load at a 4-byte aligned address
 #define LS_THREADS 1024
 #define LS_NPK ((T_NCODE + 4) / 5)
 #define LS_FLUSH 15  // vector iterations between wave reductions: 15*4 = 60 per lane and field, 64*60 < 4096 (12-bit fields)
@@ -607,38 +608,69 @@ __global__ __launch_bounds__(LS_THREADS) void k_locus_stats2(uint64_t L, uint32_
                 o_lp2 = ovf_val[obeg + 64 + lane].x;
             }
         }
-        // minority entries are few: they vote into this wave's 16-bin LDS histogram (integer atomics: exact)
-        for (uint64_t i0 = 0; i0 < nvec; i0 += 4 * 64) {
-            // four independent loads per lane in flight: the pass is a pure stream
-            uint32_t cellv[4][4], codev[4][4];
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const uint64_t i = i0 + (uint64_t)u * 64 + lane;
-                if (EB == 32) {
-                    uint4 v = make_uint4(~0u, ~0u, ~0u, ~0u);
-                    if (i < nvec) v = reinterpret_cast<const uint4 *>(wp)[i];
-                    const uint32_t xs[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-                    for (int q = 0; q < 4; q++) { cellv[u][q] = xs[q] & 0x0fffffffu; codev[u][q] = xs[q] >> 28; }
-                } else {
-                    uint32_t w0 = ~0u, w1 = ~0u, w2 = ~0u;
-                    if (i < nvec) { w0 = wp[3 * i]; w1 = wp[3 * i + 1]; w2 = wp[3 * i + 2]; }
-                    const uint32_t es[4] = {w0 & 0xffffffu, (w0 >> 24) | ((w1 & 0xffffu) << 8), (w1 >> 16) | ((w2 & 0xffu) << 16),
-                                            w2 >> 8};
-#pragma unroll
-                    for (int q = 0; q < 4; q++) { cellv[u][q] = es[q] & 0xfffffu; codev[u][q] = es[q] >> 20; }
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const uint32_t code = codev[u][q];
-                    const uint32_t cell = code < (uint32_t)T_NCODE ? cellv[u][q] : 0u;
-                    if (code < (uint32_t)T_NCODE && ((bits[cell >> 5] >> (cell & 31)) & 1u)) atomicAdd(&whist[code], 1u);
-                }
+        // minority entries are few: they vote into this wave's 16-bin LDS histogram (integer atomics: exact).  Two
+        // register buffers of four vectors (16 entries) per lane: one is processed while the other one loads.
+        struct raw_t { uint32_t w[4][EB == 32 ? 4 : 3]; uint32_t in; };  // in: bit u = vector u lies inside the column
+        // (the macros keep the buffers in named registers: no indexed local arrays).  The loads are unconditional (index
+        // clamped) and nothing touches the loaded registers before LS_PROCESS: they stay in flight meanwhile.
+#define LS_LOAD(R, I0)                                                                                           \
+        (R).in = 0;                                                                                              \
+        _Pragma("unroll") for (int u = 0; u < 4; u++) {                                                          \
+            const uint64_t i__ = (I0) + (uint64_t)u * 64 + lane;                                                 \
+            const bool in__ = i__ < nvec;                                                                        \
+            (R).in |= in__ ? (1u << u) : 0u;                                                                     \
+            const uint32_t *q__ = wp + (in__ ? i__ : 0) * (EB == 32 ? 4 : 3);                                    \
+            if (EB == 32) {                                                                                      \
+                const uint4 v__ = *reinterpret_cast<const uint4 *>(q__);                                         \
+                (R).w[u][0] = v__.x; (R).w[u][1] = v__.y; (R).w[u][2] = v__.z; (R).w[u][EB == 32 ? 3 : 0] = v__.w; \
+            } else {                                                                                             \
+                const ls_u3 v__ = *reinterpret_cast<const ls_u3 *>(q__);                                         \
+                (R).w[u][0] = v__.x; (R).w[u][1] = v__.y; (R).w[u][2] = v__.z;                                   \
+            }                                                                                                    \
+        }
+        // unpack 16 (cell, code) pairs, fetch their 16 bitmask words back to back, then vote.  Padding (and a vector
+        // beyond the column: all ones) is cell = all ones, code 15: with the bitmask in LDS its word is inside the
+        // allocation (sized for the largest cell index of the entry width) and bin 15 of the histogram is never read.
+#define LS_PROCESS(R)                                                                                            \
+        do {                                                                                                     \
+            uint32_t cell__[16], code__[16], word__[16];                                                         \
+            _Pragma("unroll") for (int u = 0; u < 4; u++) {                                                      \
+                const bool in__ = (((R).in >> u) & 1u) != 0;                                                     \
+                if (EB == 32) {                                                                                  \
+                    _Pragma("unroll") for (int q = 0; q < 4; q++) {                                              \
+                        const uint32_t x__ = in__ ? (R).w[u][EB == 32 ? q : 0] : ~0u;                            \
+                        cell__[4 * u + q] = x__ & 0x0fffffffu; code__[4 * u + q] = x__ >> 28;                    \
+                    }                                                                                            \
+                } else {                                                                                         \
+                    const uint32_t w0 = in__ ? (R).w[u][0] : ~0u, w1 = in__ ? (R).w[u][1] : ~0u,                 \
+                                   w2 = in__ ? (R).w[u][2] : ~0u;                                                \
+                    const uint32_t es__[4] = {w0 & 0xffffffu, (w0 >> 24) | ((w1 & 0xffffu) << 8),               \
+                                              (w1 >> 16) | ((w2 & 0xffu) << 16), w2 >> 8};                       \
+                    _Pragma("unroll") for (int q = 0; q < 4; q++) {                                              \
+                        cell__[4 * u + q] = es__[q] & 0xfffffu; code__[4 * u + q] = es__[q] >> 20;               \
+                    }                                                                                            \
+                }                                                                                                \
+            }                                                                                                    \
+            _Pragma("unroll") for (int e = 0; e < 16; e++) {                                                     \
+                if (!(BITS_IN_LDS && EB == 24) && code__[e] >= (uint32_t)T_NCODE) cell__[e] = 0u; /* stay in range */ \
+                word__[e] = bits[cell__[e] >> 5];                                                                \
+            }                                                                                                    \
+            _Pragma("unroll") for (int e = 0; e < 16; e++)                                                       \
+                if ((word__[e] >> (cell__[e] & 31)) & 1u) atomicAdd(&whist[code__[e]], 1u);                      \
+        } while (0)
+
+        if (nvec) {
+            raw_t ra, rb;
+            LS_LOAD(ra, 0);
+            for (uint64_t i0 = 0; i0 < nvec; i0 += 2 * 4 * 64) {
+                LS_LOAD(rb, i0 + 4 * 64);
+                LS_PROCESS(ra);
+                LS_LOAD(ra, i0 + 2 * 4 * 64);
+                LS_PROCESS(rb);
             }
         }
+#undef LS_PROCESS
+#undef LS_LOAD
         // lane k < T_NCODE takes code k (same wave wrote the bins: LDS operations of one wave complete in order)
         uint32_t mycnt = 0;
         if (lane < 16) {
@@ -1217,11 +1249,13 @@ cellector_status tiled_locus_pass(cellector_ctx *c)
                        c->c4_ent, c->flag_bits, c->hist_all, c->tab_em, (uint32_t)c->tab_em_stride, c->mask, c->ovf_n ? c->ovc_ptr : (const uint64_t *)nullptr,  \
                        c->ovc_ent, c->ovf_val, c->x_locus)
     if (lds <= 128 * 1024) {
-        const int lb = (int)(lds ? lds : 4);
         if (c->c4_bits == 24) {
+            // the whole 2^20-cell bitmask: a padding entry (cell = all ones) then reads inside the allocation
+            const int lb = 128 * 1024;
             HIPCHK(c, hipFuncSetAttribute((const void *)k_locus_stats2<true, 24>, hipFuncAttributeMaxDynamicSharedMemorySize, lb));
             LAUNCH_LS(true, 24, grid, lb);
         } else {
+            const int lb = (int)(lds ? lds : 4);
             HIPCHK(c, hipFuncSetAttribute((const void *)k_locus_stats2<true, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, lb));
             LAUNCH_LS(true, 32, grid, lb);
         }
