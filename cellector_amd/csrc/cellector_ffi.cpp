@@ -160,6 +160,10 @@ cellector_status cellector_set_option(cellector_ctx *c, const char *key, int64_t
     else if (!strcmp(key, "timing")) c->timing = v != 0;
     else if (!strcmp(key, "keep_coo")) c->keep_coo = v != 0;
     else if (!strcmp(key, "overlap")) c->overlap = v != 0;
+    else if (!strcmp(key, "locus_mode")) {
+        if (v < 0 || v > 2) return ctx_fail(c, CELLECTOR_EINVAL, "locus_mode must be 0 (automatic), 1 (stream) or 2 (minority-driven)");
+        c->locus_mode = (int)v;
+    }
     else if (!strcmp(key, "compact_bits")) {
         if (v != 0 && v != 32) return ctx_fail(c, CELLECTOR_EINVAL, "compact_bits must be 0 (automatic) or 32");
         c->c4_bits_opt = (int)v;
@@ -449,6 +453,7 @@ cellector_status cellector_em_threshold(cellector_ctx *c, double iqr_multiple)
     // exact median / R-8 quartiles / threshold, all on the device (no host round trip in this phase)
     CHK(select_threshold(c, c->x_norm, n, iqr_multiple));
     HIPCHK(c, hipMemsetAsync(c->x_locus + (uint64_t)LB_PLANES * c->L, 0, LC_COUNTERS * 8, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_counters + DC_N_MIN, 0, sizeof(uint32_t), c->stream));
     CHK(launch_flag(c, c->sel_out + 10));
     if (c->engine == 2) CHK(tiled_locus_pass(c));
     else CHK(launch_locus_stats(c));

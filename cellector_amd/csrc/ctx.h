@@ -26,6 +26,9 @@ enum { LC_N_NEW = 0, LC_N_RESCUED = 1, LC_N_EXCLUDED = 2, LC_COUNTERS = 8 };
 // PASS1 exchange buffer layout (f64): 5 planes of total_loci
 enum { P1_CELLS_REF = 0, P1_CELLS_ALT = 1, P1_SUM_REF = 2, P1_SUM_ALT = 3, P1_ENTRIES = 4, P1_PLANES = 5 };
 
+// d_counters slots (u32)
+enum { DC_N_FILTERED = 0, DC_N_MIN = 4 /* members of this shard's new exclusion set (k_flag) */ };
+
 #define LF_TABLE_N 171  // ln(FCACHE[0..170]) — statrs ln_factorial cache, SURVEY Appendix B.2
 
 struct KernelTimer {
@@ -116,6 +119,11 @@ struct cellector_ctx {
     uint32_t *masked_cnt = nullptr;  // [nloc] entries of the cell at masked loci
     uint32_t *flag_bits = nullptr;   // [ceil(nloc/32)] new exclusion set as a bitmask
     uint64_t n_masked_loci = 0;
+    uint32_t *minlist = nullptr;     // [nloc] local ids of the cells of the new exclusion set (arbitrary order)
+    uint32_t *hist_min = nullptr;    // [LR_SUB][L][16] regular entries of minority cells per (locus, code), partial planes
+    uint32_t *roff = nullptr;        // [nloc][R+1] offsets of the locus ranges inside each by-cell CSR row
+    int locus_mode = 0;              // option "locus_mode": 0 = chosen on the device per iteration, 1 = stream the compact CSC,
+                                     // 2 = minority-driven tally over the by-cell CSR
 
     // order-statistic workspace
     uint32_t *sel_hist = nullptr;   // [SEL_T][256]

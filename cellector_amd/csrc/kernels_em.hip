@@ -86,13 +86,20 @@ __global__ __launch_bounds__(BLOCK) void k_cell_ll(uint64_t n_rows, const uint64
 // new_excluded = {i : norm_i < threshold} (main.rs:330-332) and the symmetric-difference counts
 // (main.rs:333-334) accumulated as f64 into the LOCUS exchange buffer's counter slots.
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_flag(uint64_t n, const double *__restrict__ norm, const double *__restrict__ d_thr,
-                                              const uint8_t *__restrict__ old_flags, uint8_t *__restrict__ new_flags,
-                                              double *__restrict__ counters)
+#define FLAG_THREADS 1024
+__global__ __launch_bounds__(FLAG_THREADS) void k_flag(uint64_t n, const double *__restrict__ norm, const double *__restrict__ d_thr,
+                                                       const uint8_t *__restrict__ old_flags, uint8_t *__restrict__ new_flags,
+                                                       double *__restrict__ counters, uint32_t *__restrict__ minlist /*may be null*/,
+                                                       uint32_t *__restrict__ n_min)
 {
+    __shared__ uint32_t s_wave[FLAG_THREADS / 64];
+    __shared__ uint32_t s_base;
     const double thr = *d_thr;  // computed on the device by k_threshold
+    // a block takes a contiguous span of cells (a multiple of the block size), wave w of it the 64-cell pieces w, w+16, ...
+    const uint64_t span = ((n + gridDim.x - 1) / gridDim.x + FLAG_THREADS - 1) / FLAG_THREADS * FLAG_THREADS;
+    const uint64_t beg = min(n, (uint64_t)blockIdx.x * span), end = min(n, beg + span);
     uint32_t c_new = 0, c_res = 0, c_exc = 0;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    for (uint64_t i = beg + threadIdx.x; i < end; i += FLAG_THREADS) {
         const bool nf = norm[i] < thr;
         const bool of = old_flags[i] != 0;
         new_flags[i] = nf ? 1 : 0;
@@ -108,6 +115,31 @@ __global__ __launch_bounds__(256) void k_flag(uint64_t n, const double *__restri
         if (c_new) atomicAdd(&counters[LC_N_NEW], (double)c_new);
         if (c_res) atomicAdd(&counters[LC_N_RESCUED], (double)c_res);
         if (c_exc) atomicAdd(&counters[LC_N_EXCLUDED], (double)c_exc);
+        s_wave[threadIdx.x >> 6] = c_exc;
+    }
+    if (!minlist) return;
+    // The members of the new exclusion set as a list (engine 2's minority-driven locus tally): ONE atomic per block
+    // reserves the block's slots (per-wave atomics on the one counter serialise: 0.17 ms at 1M cells), then a second
+    // walk over the span (L2-hot) fills them.  The list's order depends on the block order only through the bases, and
+    // only order-independent integer tallies are derived from it.
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t tot = 0;
+        for (int w = 0; w < FLAG_THREADS / 64; w++) {
+            const uint32_t x = s_wave[w];
+            s_wave[w] = tot;
+            tot += x;
+        }
+        s_base = tot ? atomicAdd(n_min, tot) : 0u;
+    }
+    __syncthreads();
+    uint32_t pos = s_base + s_wave[threadIdx.x >> 6];
+    const uint64_t end_round = beg + (end - beg + 63) / 64 * 64;  // whole waves take part in the ballot
+    for (uint64_t i = beg + threadIdx.x; i < end_round; i += FLAG_THREADS) {
+        const bool nf = i < end && norm[i] < thr;
+        const unsigned long long m = __ballot(nf);
+        if (nf) minlist[pos + (uint32_t)__popcll(m & ((1ull << (threadIdx.x & 63)) - 1ull))] = (uint32_t)i;
+        pos += (uint32_t)__popcll(m);
     }
 }
 
@@ -324,8 +356,9 @@ cellector_status launch_cell_ll(cellector_ctx *c, const double2 *ab, double *nor
 cellector_status launch_flag(cellector_ctx *c, const double *d_thr)
 {
     if (c->nloc == 0) return CELLECTOR_OK;
-    hipLaunchKernelGGL(k_flag, dim3(grid_for(c->nloc, 256 * 16, 1024)), dim3(256), 0, c->stream, c->nloc,
-                       c->x_norm + c->cell_begin, d_thr, c->flags, c->flags_new, c->x_locus + LB_PLANES * c->L);
+    hipLaunchKernelGGL(k_flag, dim3(grid_for(c->nloc, FLAG_THREADS * 4, 256)), dim3(FLAG_THREADS), 0, c->stream, c->nloc,
+                       c->x_norm + c->cell_begin, d_thr, c->flags, c->flags_new, c->x_locus + LB_PLANES * c->L,
+                       c->tiled_ready ? c->minlist : (uint32_t *)nullptr, c->d_counters + DC_N_MIN);
     HIPCHK(c, hipGetLastError());
     return CELLECTOR_OK;
 }

@@ -540,6 +540,14 @@ __global__ void k_pack_flag_bits(uint64_t n, const uint8_t *__restrict__ flags, 
     if ((threadIdx.x & 31) == 0 && w * 32 < n) bits[w] = (uint32_t)(m >> (threadIdx.x & 32));
 }
 
+// Form of the locus pass, decided on the device from this shard's exclusion-set size (see k_minority_hist below)
+#define LM_NUM 1  // minority-driven when n_min / nloc <= LM_NUM / LM_DEN
+#define LM_DEN 8
+__device__ __forceinline__ bool locus_by_minority(int mode, uint32_t n_min, uint64_t nloc)
+{
+    return mode == 2 || (mode == 0 && (uint64_t)n_min * LM_DEN <= nloc * LM_NUM);
+}
+
 struct __attribute__((packed, aligned(4))) ls_u3 { uint32_t x, y, z; };  // 12-byte load at a 4-byte aligned address
 #define LS_THREADS 1024
 #define LS_NPK ((T_NCODE + 4) / 5)
@@ -549,14 +557,10 @@ __global__ __launch_bounds__(LS_THREADS) void k_locus_stats2(uint64_t L, uint32_
                                                              const uint64_t *__restrict__ c4_ptr,
                                                              const uint32_t *__restrict__ c4_ent,
                                                              const uint32_t *__restrict__ flag_bits,
-                                                             const uint32_t *__restrict__ hist_all,
-                                                             const double *__restrict__ tab, uint32_t tab_stride,
-                                                             const uint8_t *__restrict__ mask,
-                                                             const uint64_t *__restrict__ ovc_ptr /*null: no overflow*/,
-                                                             const uint64_t *__restrict__ ovc_ent,
-                                                             const double2 *__restrict__ ovf_val,
-                                                             double *__restrict__ out)
+                                                             uint32_t *__restrict__ hist_min /*plane 0*/, int locus_mode,
+                                                             uint64_t nloc, const uint32_t *__restrict__ n_min)
 {
+    if (locus_by_minority(locus_mode, *n_min, nloc)) return;  // k_minority_ranges counts this iteration
     extern __shared__ uint32_t s_bits[];
     __shared__ uint32_t s_whist[LS_THREADS / 64][16];
     if (threadIdx.x < (LS_THREADS / 64) * 16) (&s_whist[0][0])[threadIdx.x] = 0;
@@ -570,43 +574,15 @@ __global__ __launch_bounds__(LS_THREADS) void k_locus_stats2(uint64_t L, uint32_
     const uint64_t nwaves = (uint64_t)gridDim.x * (LS_THREADS / 64);
     // the column pointers of a locus are requested one locus ahead, its per-code constants at the top of its turn: a
     // short column (a small shard) then costs one memory latency, not three in a row
-    uint64_t n_c4b = 0, n_c4e = 0, n_ob = 0, n_oe = 0;
-    if (wave0 < L) {
-        n_c4b = c4_ptr[wave0]; n_c4e = c4_ptr[wave0 + 1];
-        if (ovc_ptr) { n_ob = ovc_ptr[wave0]; n_oe = ovc_ptr[wave0 + 1]; }
-    }
+    uint64_t n_c4b = 0, n_c4e = 0;
+    if (wave0 < L) { n_c4b = c4_ptr[wave0]; n_c4e = c4_ptr[wave0 + 1]; }
     for (uint64_t l = wave0; l < L; l += nwaves) {
         // columns are padded to groups of four entries (code 15 = no entry): 16 bytes at 32 bits, 12 bytes at 24 bits
         const uint64_t vbeg = n_c4b >> 2, nvec = (n_c4e >> 2) - vbeg;
         const uint32_t *wp = c4_ent + vbeg * (EB == 32 ? 4 : 3);
-        const uint64_t obeg = n_ob, oend = n_oe;
         {
             const uint64_t ln = min(l + nwaves, L - 1);  // clamped: the last round re-reads a valid locus
             n_c4b = c4_ptr[ln]; n_c4e = c4_ptr[ln + 1];
-            if (ovc_ptr) { n_ob = ovc_ptr[ln]; n_oe = ovc_ptr[ln + 1]; }
-        }
-        // per-code constants of this locus (lanes 0..13): static histogram, this pass' log-pmf, the loci mask
-        const bool live = mask[l] != 0;
-        uint32_t h_all = 0;
-        double t_code = 0.0;
-        if (lane < T_NCODE) {
-            h_all = hist_all[l * T_NCODE + lane];
-            // (element stride 2 when the table holds (log-pmf, expected) pairs)
-            t_code = tab[((l / T_BL) * TAB_ELEMS + (uint64_t)lane * T_BL + (l % T_BL)) * tab_stride];
-        }
-        // this locus' overflow entries (alt+ref == 0 or > T_K; ~1 %): their stored log-pmfs are only gathered.  The
-        // first 128 are requested now and consumed after the column has been streamed.
-        uint64_t o_en = 0, o_en2 = 0;
-        double o_lp = 0.0, o_lp2 = 0.0;
-        if (ovc_ptr) {
-            if (obeg + lane < oend) {
-                o_en = ovc_ent[obeg + lane];
-                o_lp = ovf_val[obeg + lane].x;
-            }
-            if (obeg + 64 + lane < oend) {
-                o_en2 = ovc_ent[obeg + 64 + lane];
-                o_lp2 = ovf_val[obeg + 64 + lane].x;
-            }
         }
         // minority entries are few: they vote into this wave's 16-bin LDS histogram (integer atomics: exact).  Two
         // register buffers of four vectors (16 entries) per lane: one is processed while the other one loads.
@@ -671,62 +647,204 @@ __global__ __launch_bounds__(LS_THREADS) void k_locus_stats2(uint64_t L, uint32_
         }
 #undef LS_PROCESS
 #undef LS_LOAD
-        // lane k < T_NCODE takes code k (same wave wrote the bins: LDS operations of one wave complete in order)
-        uint32_t mycnt = 0;
+        // the wave's bins are this locus' minority counts per code: plane 0 of hist_min (same wave wrote the bins: LDS
+        // operations of one wave complete in order); k_locus_finalize turns them into the pass' outputs
         if (lane < 16) {
-            mycnt = whist[lane];
+            hist_min[l * 16 + lane] = whist[lane];
             whist[lane] = 0;
         }
-        double cmin = 0.0, cmaj = 0.0;
-        uint32_t nmin = 0, amin = 0, rmin = 0;
-        if (lane < T_NCODE) {
-            nmin = mycnt;
-            amin = mycnt * T_A_OF[lane];
-            rmin = mycnt * T_R_OF[lane];
-            if (live) {
-                cmin = (double)mycnt * t_code;
-                cmaj = (double)(h_all - mycnt) * t_code;
-            }
-        }
-        // fixed-shape sum over the codes (lanes 0..13): deterministic
-        cmin = wave_sum(cmin);
-        cmaj = wave_sum(cmaj);
-        nmin = wave_sum_u32(nmin);
-        amin = wave_sum_u32(amin);
-        rmin = wave_sum_u32(rmin);
-        // overflow part (wave-uniform trip count); same sums as the regular part, added once per plane
-        double o_cmin = 0.0, o_cmaj = 0.0;
-        uint32_t o_nmin = 0;
-        uint64_t o_amin = 0, o_rmin = 0;
-        for (uint64_t i0 = obeg; i0 < oend; i0 += 64) {
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// locus pass, minority-driven form.  Everything the pass reports follows from the per-(locus, code) counts of the
+// MINORITY cells' regular entries (the majority side is the static histogram minus that), and the exclusion set is a
+// small part of the cells (below the lower quartile by construction, a few percent in practice).  So instead of
+// streaming the whole compact CSC past the exclusion bitmask, walk only the by-cell CSR rows of the excluded cells.
+// Global atomics are out (measured: 2.7e10 scattered u32 atomics/s on this chip, 3.7 ms for cfg4's 1e8 entries), so
+// the counting happens in LDS: the loci are cut into ranges of LR_LOCI, a workgroup owns one range and one of LR_SUB
+// subsets of the excluded cells, finds every such cell's entries of its range through a per-(cell, range) offset
+// table built at ingest (roff), counts them into a u32 histogram in LDS (integer atomics: exact, order independent)
+// and writes the histogram out as one of LR_SUB partial planes; k_locus_finalize adds the planes.  The result is
+// bit-identical to the streamed form.  Cost: the excluded cells' entries instead of all of them.  The form is chosen
+// on the device from this shard's exclusion-set size (no host round trip); the kernels of the other form return at once.
+// ---------------------------------------------------------------------------------------------------------
+#define LR_LOCI 1024     // loci per range: the LDS histogram is LR_LOCI x 16 codes x u32 = 64 KB
+#define LR_SUB 4         // subsets of the exclusion set (partial planes)
+#define LR_THREADS 1024
+#define LR_GROUP 16      // lanes per (cell, range) segment: ~10 entries at 1 % density
+
+// roff[cell][r] = number of the row's entries with locus < r * LR_LOCI, r = 0..R (row sorted by locus).  Wave per row.
+__global__ __launch_bounds__(256) void k_range_offsets(uint64_t n_rows, uint32_t R, const uint64_t *__restrict__ csr_ptr,
+                                                       const uint64_t *__restrict__ csr_ent, uint32_t *__restrict__ roff)
+{
+    const int lane = threadIdx.x & 63;
+    const uint64_t wave0 = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (uint64_t)gridDim.x * 4;
+    for (uint64_t row = wave0; row < n_rows; row += nwaves) {
+        const uint64_t beg = csr_ptr[row], end = csr_ptr[row + 1];
+        uint32_t *o = roff + row * (R + 1);
+        // position i (0..len): ranges above that of entry i-1 up to that of entry i start at i (entry -1: range -1,
+        // entry len: range R)
+        for (uint64_t i0 = beg; i0 <= end; i0 += 64) {
             const uint64_t i = i0 + lane;
-            if (i0 == obeg + 64) {
-                o_en = o_en2;
-                o_lp = o_lp2;
-            } else if (i0 != obeg && i < oend) {
-                o_en = ovc_ent[i];
-                o_lp = ovf_val[i].x;
+            if (i > end) continue;
+            const int r_prev = i > beg ? (int)(ENT_IDX(csr_ent[i - 1]) / LR_LOCI) : -1;
+            const int r_here = i < end ? (int)(ENT_IDX(csr_ent[i]) / LR_LOCI) : (int)R;
+            for (int r = r_prev + 1; r <= r_here; r++) o[r] = (uint32_t)(i - beg);
+        }
+    }
+}
+
+__global__ __launch_bounds__(LR_THREADS) void k_minority_ranges(int locus_mode, uint64_t nloc, uint64_t L, uint32_t R,
+                                                               const uint32_t *__restrict__ n_min_p,
+                                                               const uint32_t *__restrict__ minlist,
+                                                               const uint64_t *__restrict__ csr_ptr,
+                                                               const uint32_t *__restrict__ roff,
+                                                               const uint64_t *__restrict__ csr_ent,
+                                                               uint32_t *__restrict__ hist_min /*[LR_SUB][L][16]*/)
+{
+    const uint32_t n_min = *n_min_p;
+    if (!locus_by_minority(locus_mode, n_min, nloc)) return;
+    __shared__ uint32_t s_hist[LR_LOCI * 16];
+    __shared__ uint64_t s_beg[LR_THREADS];
+    __shared__ uint32_t s_len[LR_THREADS];
+    const uint32_t tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+    const uint32_t r = blockIdx.x % R, sub = blockIdx.x / R;
+    const uint32_t per = (n_min + LR_SUB - 1) / LR_SUB;
+    const uint32_t k0 = min(n_min, sub * per), k1 = min(n_min, k0 + per);
+    const uint32_t l0 = r * LR_LOCI;
+    for (uint32_t i = tid; i < LR_LOCI * 16; i += LR_THREADS) s_hist[i] = 0;
+    const uint32_t grp = lane / LR_GROUP, gl = lane % LR_GROUP;
+    for (uint32_t kb = k0; kb < k1; kb += LR_THREADS) {
+        // 1. one excluded cell per thread: where its entries of this range start, and how many there are
+        {
+            const uint32_t k = kb + tid;
+            uint64_t b = 0;
+            uint32_t n = 0;
+            if (k < k1) {
+                const uint32_t cell = minlist[k];
+                const uint32_t *o = roff + (uint64_t)cell * (R + 1) + r;
+                const uint32_t o0 = o[0], o1 = o[1];
+                b = csr_ptr[cell] + o0;
+                n = o1 - o0;
             }
-            if (i < oend) {
-                const uint32_t cell = ENT_IDX(o_en);
-                const bool minority = ((bits[cell >> 5] >> (cell & 31)) & 1u) != 0;
-                if (minority) { o_amin += ENT_ALT(o_en); o_rmin += ENT_REF(o_en); }
-                if (live) {
-                    if (minority) { o_cmin += o_lp; o_nmin++; } else o_cmaj += o_lp;
+            s_beg[tid] = b;
+            s_len[tid] = n;
+        }
+        __syncthreads();  // (also: the histogram is zeroed)
+        // 2. a wave takes 64 of the segments, LR_GROUP lanes per segment, four segment quads per trip so that four
+        //    loads per lane are in flight; the rare segment longer than LR_GROUP finishes in a loop
+        for (uint32_t q0 = 0; q0 < 64 / (64 / LR_GROUP); q0 += 4) {
+            uint64_t e[4], sb[4];
+            uint32_t sn[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const uint32_t seg = wv * 64 + (q0 + u) * (64 / LR_GROUP) + grp;
+                sb[u] = s_beg[seg];
+                sn[u] = s_len[seg];
+                e[u] = gl < sn[u] ? csr_ent[sb[u] + gl] : 0;  // 0: alt + ref == 0, not regular
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                if (ent_regular(e[u])) atomicAdd(&s_hist[(ENT_IDX(e[u]) - l0) * 16 + ent_code(e[u])], 1u);
+                for (uint32_t j = gl + LR_GROUP; j < sn[u]; j += LR_GROUP) {
+                    const uint64_t x = csr_ent[sb[u] + j];
+                    if (ent_regular(x)) atomicAdd(&s_hist[(ENT_IDX(x) - l0) * 16 + ent_code(x)], 1u);
                 }
             }
         }
-        if (oend != obeg) {
-            o_cmin = wave_sum(o_cmin); o_cmaj = wave_sum(o_cmaj);
-            o_nmin = wave_sum_u32(o_nmin); o_amin = wave_sum_u64(o_amin); o_rmin = wave_sum_u64(o_rmin);
+        __syncthreads();  // segments consumed before the next batch overwrites them
+    }
+    __syncthreads();
+    // 3. this subset's plane of the range
+    const uint64_t nl = min((uint64_t)LR_LOCI, L - l0);
+    uint32_t *dst = hist_min + ((uint64_t)sub * L + l0) * 16;
+    for (uint32_t i = tid; i < nl * 16; i += LR_THREADS) dst[i] = s_hist[i];
+}
+
+// Outputs of the locus pass from the minority counts (both forms end here, so they agree to the bit).  16 lanes per
+// locus: lane j < 14 takes code j's count (sum of the planes), static histogram and log-pmf; the locus' overflow entries
+// (alt+ref == 0 or > T_K; ~1 %, their log-pmfs stored by k_ovf_values) are walked 16 at a time; per-lane partial results
+// are added by a 4-step butterfly over the 16 lanes (fixed shape: deterministic).
+#define LF_LANES 16
+template <typename T>
+__device__ __forceinline__ T group16_sum(T v)
+{
+#pragma unroll
+    for (int m = LF_LANES / 2; m > 0; m >>= 1) v += __shfl_xor(v, m, LF_LANES);
+    return v;
+}
+__global__ __launch_bounds__(256) void k_locus_finalize(uint64_t L, int locus_mode, uint64_t nloc,
+                                                        const uint32_t *__restrict__ n_min_p,
+                                                        const uint32_t *__restrict__ hist_min,
+                                                        const uint32_t *__restrict__ flag_bits,
+                                                        const uint32_t *__restrict__ hist_all,
+                                                        const double *__restrict__ tab, uint32_t tab_stride,
+                                                        const uint8_t *__restrict__ mask,
+                                                        const uint64_t *__restrict__ ovc_ptr /*null: no overflow*/,
+                                                        const uint64_t *__restrict__ ovc_ent,
+                                                        const double2 *__restrict__ ovf_val, double *__restrict__ out)
+{
+    const int nplanes = locus_by_minority(locus_mode, *n_min_p, nloc) ? LR_SUB : 1;
+    const uint32_t j = threadIdx.x % LF_LANES;
+    const uint64_t l_raw = ((uint64_t)blockIdx.x * 256 + threadIdx.x) / LF_LANES;
+    const bool in = l_raw < L;
+    const uint64_t l = in ? l_raw : L - 1;  // whole waves stay in the butterflies
+    const bool live = mask[l] != 0;
+    uint64_t obeg = 0, oend = 0;
+    if (ovc_ptr) { obeg = ovc_ptr[l]; oend = ovc_ptr[l + 1]; }
+    double cmin = 0.0, cmaj = 0.0;
+    uint32_t nmin = 0;
+    uint64_t amin = 0, rmin = 0;
+    if (j < T_NCODE) {
+        uint32_t cnt = 0;
+        for (int p = 0; p < nplanes; p++) cnt += hist_min[((uint64_t)p * L + l) * 16 + j];
+        const uint32_t h_all = hist_all[l * T_NCODE + j];
+        // (element stride 2 when the table holds (log-pmf, expected) pairs)
+        const double t_code = tab[((l / T_BL) * TAB_ELEMS + (uint64_t)j * T_BL + (l % T_BL)) * tab_stride];
+        amin = (uint64_t)cnt * T_A_OF[j];
+        rmin = (uint64_t)cnt * T_R_OF[j];
+        if (live) {
+            nmin = cnt;
+            cmin = (double)cnt * t_code;
+            cmaj = (double)(h_all - cnt) * t_code;
         }
-        if (lane == 0) {
-            out[LB_CONTRIB_MIN * L + l] = cmin + o_cmin;
-            out[LB_CONTRIB_MAJ * L + l] = cmaj + o_cmaj;
-            out[LB_CELLS_MIN * L + l] = (live ? (double)nmin : 0.0) + (double)o_nmin;
-            out[LB_ALT_MIN * L + l] = (double)amin + (double)o_amin;
-            out[LB_REF_MIN * L + l] = (double)rmin + (double)o_rmin;
+    }
+    // overflow entries: four independent (entry, value) loads per lane in flight, then their exclusion-bitmask words
+    for (uint64_t i0 = obeg + j; i0 < oend; i0 += 4 * LF_LANES) {
+        uint64_t en[4];
+        double lp[4];
+        uint32_t w[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint64_t i = i0 + (uint64_t)u * LF_LANES;
+            const bool ok = i < oend;
+            en[u] = ok ? ovc_ent[i] : ~0ull;
+            lp[u] = ok ? ovf_val[i].x : 0.0;
         }
+#pragma unroll
+        for (int u = 0; u < 4; u++) w[u] = en[u] != ~0ull ? flag_bits[ENT_IDX(en[u]) >> 5] : 0u;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            if (en[u] == ~0ull) continue;
+            const bool minority = ((w[u] >> (ENT_IDX(en[u]) & 31)) & 1u) != 0;
+            if (minority) { amin += ENT_ALT(en[u]); rmin += ENT_REF(en[u]); }
+            if (live) {
+                if (minority) { cmin += lp[u]; nmin++; } else cmaj += lp[u];
+            }
+        }
+    }
+    cmin = group16_sum(cmin);
+    cmaj = group16_sum(cmaj);
+    nmin = group16_sum(nmin);
+    amin = group16_sum(amin);
+    rmin = group16_sum(rmin);
+    if (in && j == 0) {
+        out[LB_CONTRIB_MIN * L + l] = cmin;
+        out[LB_CONTRIB_MAJ * L + l] = cmaj;
+        out[LB_CELLS_MIN * L + l] = (double)nmin;
+        out[LB_ALT_MIN * L + l] = (double)amin;
+        out[LB_REF_MIN * L + l] = (double)rmin;
     }
 }
 
@@ -994,7 +1112,7 @@ void tiled_free(cellector_ctx *c)
     dev_free(c->c4_ptr); dev_free(c->c4_ent); dev_free(c->ovc_ptr); dev_free(c->ovc_ent);
     dev_free(c->hist_all); dev_free(c->tab); dev_free(c->part); dev_free(c->ab3);
     dev_free(c->masked_cnt); dev_free(c->flag_bits); dev_free(c->ovf_perm); dev_free(c->ovf_val); dev_free(c->ovf_tab);
-    dev_free(c->ovf_sum); dev_free(c->ovf_nmask);
+    dev_free(c->ovf_sum); dev_free(c->ovf_nmask); dev_free(c->minlist); dev_free(c->hist_min); dev_free(c->roff);
     c->tiled_ready = false;
     c->ovf_n = 0; c->n_masked_loci = 0;
 }
@@ -1119,6 +1237,16 @@ cellector_status tiled_build(cellector_ctx *c)
     CHK(dev_alloc(c, &c->ab3, 3 * L));
     CHK(dev_alloc(c, &c->masked_cnt, nloc));
     CHK(dev_alloc(c, &c->flag_bits, (nloc + 31) / 32 + 1));
+    CHK(dev_alloc(c, &c->minlist, nloc));
+    CHK(dev_alloc(c, &c->hist_min, (uint64_t)LR_SUB * L * 16));
+    {
+        const uint32_t R = (uint32_t)((L + LR_LOCI - 1) / LR_LOCI);
+        CHK(dev_alloc(c, &c->roff, nloc * (R + 1)));
+        if (nloc)
+            hipLaunchKernelGGL(k_range_offsets, dim3(gcap(nloc, 4)), dim3(256), 0, c->stream, nloc, R, c->csr_ptr, c->csr_ent,
+                               c->roff);
+        HIPCHK(c, hipGetLastError());
+    }
     HIPCHK(c, hipMemsetAsync(c->masked_cnt, 0, (nloc ? nloc : 1) * 4, c->stream));
     HIPCHK(c, hipMemsetAsync(c->flag_bits, 0, ((nloc + 31) / 32 + 1) * 4, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1246,9 +1374,10 @@ cellector_status tiled_locus_pass(cellector_ctx *c)
     if (grid > need) grid = (unsigned)(need ? need : 1);
 #define LAUNCH_LS(INLDS, EBV, GRID, LDSB)                                                                              \
     hipLaunchKernelGGL((k_locus_stats2<INLDS, EBV>), dim3(GRID), dim3(LS_THREADS), LDSB, c->stream, c->L, words, c->c4_ptr, \
-                       c->c4_ent, c->flag_bits, c->hist_all, c->tab_em, (uint32_t)c->tab_em_stride, c->mask, c->ovf_n ? c->ovc_ptr : (const uint64_t *)nullptr,  \
-                       c->ovc_ent, c->ovf_val, c->x_locus)
-    if (lds <= 128 * 1024) {
+                       c->c4_ent, c->flag_bits, c->hist_min, c->locus_mode, c->nloc, c->d_counters + DC_N_MIN)
+    if (c->locus_mode == 2) {
+        // minority-driven form forced: nothing to stream
+    } else if (lds <= 128 * 1024) {
         if (c->c4_bits == 24) {
             // the whole 2^20-cell bitmask: a padding entry (cell = all ones) then reads inside the allocation
             const int lb = 128 * 1024;
@@ -1263,6 +1392,17 @@ cellector_status tiled_locus_pass(cellector_ctx *c)
         LAUNCH_LS(false, 32, grid * 2, 4);  // more than 2^20 cells per shard: 32-bit entries, bitmask read from L2
     }
 #undef LAUNCH_LS
+    if (c->nloc == 0)  // an empty shard: no kernel fills the planes
+        HIPCHK(c, hipMemsetAsync(c->hist_min, 0, (uint64_t)LR_SUB * c->L * 16 * sizeof(uint32_t), c->stream));
+    if (c->locus_mode != 1 && c->nloc) {
+        const uint32_t R = (uint32_t)((c->L + LR_LOCI - 1) / LR_LOCI);
+        hipLaunchKernelGGL(k_minority_ranges, dim3(R * LR_SUB), dim3(LR_THREADS), 0, c->stream, c->locus_mode, c->nloc, c->L, R,
+                           c->d_counters + DC_N_MIN, c->minlist, c->csr_ptr, c->roff, c->csr_ent, c->hist_min);
+    }
+    hipLaunchKernelGGL(k_locus_finalize, dim3(gcap(c->L * LF_LANES, 256, 0x7fffffffu)), dim3(256), 0, c->stream, c->L, c->locus_mode,
+                       c->nloc, c->d_counters + DC_N_MIN, c->hist_min, c->flag_bits, c->hist_all, c->tab_em,
+                       (uint32_t)c->tab_em_stride, c->mask, c->ovf_n ? c->ovc_ptr : (const uint64_t *)nullptr, c->ovc_ent,
+                       c->ovf_val, c->x_locus);
     timer_end(c, CELLECTOR_K_LOCUS_STATS);
     HIPCHK(c, hipGetLastError());
     return CELLECTOR_OK;

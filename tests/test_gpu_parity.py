@@ -148,6 +148,37 @@ def test_wide_compact_entries(mods):
     g.close()
 
 
+def test_locus_pass_forms_are_bit_identical(mods):
+    """Engine 2 tallies the per-locus statistics either by streaming the compact CSC past the exclusion bitmask
+    (locus_mode 1) or by walking only the excluded cells' rows into an integer histogram (locus_mode 2; mode 0 picks
+    one on the device per iteration).  Same counts, same fixed-shape f64 sums: every output must agree to the bit,
+    and each form must agree with the oracle."""
+    if mods["engine"] != 2:
+        pytest.skip("engine 2 option")
+    lo, ce, al, re = mods["synth"].generate_coo(1500, 1100, 0.1, seed=33, minority_fraction=0.2)
+    runs = []
+    for mode in (1, 2, 0):
+        g = mods["Cellector"](0)
+        g.set_option("locus_mode", mode)
+        g.load_coo(1500, 1100, lo, ce, al, re)
+        o = mods["ob"].Oracle.from_coo(1500, 1100, lo, ce, al, re)
+        outs = []
+        for _ in range(30):
+            sg, so = g.em_iteration(5.0), o.em_iteration(5.0)
+            _check_iteration(g, o, sg, so)
+            outs.append(g.locus_outputs())
+            if not sg.any_change:
+                break
+        runs.append(outs)
+        g.close()
+        o.close()
+    assert len(runs[0]) == len(runs[1]) == len(runs[2])
+    for a, b, c in zip(*runs):
+        for k in a:
+            assert np.array_equal(a[k], b[k]), k
+            assert np.array_equal(a[k], c[k]), k
+
+
 def test_ll_pass_under_caller_alpha_beta_and_mask(mods):
     g, o, _ = _case(mods, 1500, 800, 0.1, seed=3)
     rng = np.random.default_rng(0)
