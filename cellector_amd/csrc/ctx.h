@@ -105,8 +105,9 @@ struct cellector_ctx {
     uint32_t *ovf_perm = nullptr;    // [ovf_n] by-cell position -> by-locus position
     double *ovf_tab = nullptr;       // [L][64] per-locus cumulative-log / expected tables for overflow entries
     double2 *ovf_val = nullptr;      // [3][ovf_n] (log-pmf, expected term) of overflow entries, by-locus order
-    uint32_t *ovf_nmask = nullptr;   // [L] which alt+ref totals (4..17) occur among the locus' overflow entries
+    double *ovf_lp = nullptr;        // [ovf_n] the EM pass' overflow log-pmfs alone, by-locus order (locus pass)
     double *ovf_sum = nullptr;       // [3][2][nloc] per-cell sums of the overflow values (ll, expected) per table set
+    uint32_t *ovf_nmask = nullptr;   // [L] which alt+ref totals (4..17) occur among the locus' overflow entries
     uint64_t *c4_ptr = nullptr;      // [L+1] compact CSC of regular entries
     uint32_t *c4_ent = nullptr;      // 32-bit entries cell_local | code << 28, or 24-bit cell | code << 20 (c4_bits)
     int c4_bits = 32;
@@ -121,6 +122,9 @@ struct cellector_ctx {
     uint64_t n_masked_loci = 0;
     uint32_t *minlist = nullptr;     // [nloc] local ids of the cells of the new exclusion set (arbitrary order)
     uint32_t *hist_min = nullptr;    // [LR_SUB][L][16] regular entries of minority cells per (locus, code), partial planes
+    uint32_t *mroff = nullptr;       // [R+1][mroff_cap] the excluded cells' offset rows, transposed (per iteration)
+    uint64_t *mbeg = nullptr;        // [mroff_cap] start of the excluded cells' rows in csr_ent
+    uint64_t mroff_cap = 0;
     uint32_t *roff = nullptr;        // [nloc][R+1] offsets of the locus ranges inside each by-cell CSR row
     int locus_mode = 0;              // option "locus_mode": 0 = chosen on the device per iteration, 1 = stream the compact CSC,
                                      // 2 = minority-driven tally over the by-cell CSR

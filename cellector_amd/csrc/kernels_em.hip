@@ -107,31 +107,35 @@ __global__ __launch_bounds__(FLAG_THREADS) void k_flag(uint64_t n, const double 
         c_res += (of && !nf) ? 1u : 0u;
         c_exc += nf ? 1u : 0u;
     }
-    // one f64 atomic per wave and counter (integers: exact and order independent)
+    // one f64 atomic per BLOCK and counter (integers: exact and order independent; atomics on one address serialise)
+    __shared__ uint32_t s_new[FLAG_THREADS / 64], s_res[FLAG_THREADS / 64];
     c_new = wave_sum_u32(c_new);
     c_res = wave_sum_u32(c_res);
     c_exc = wave_sum_u32(c_exc);
     if ((threadIdx.x & 63) == 0) {
-        if (c_new) atomicAdd(&counters[LC_N_NEW], (double)c_new);
-        if (c_res) atomicAdd(&counters[LC_N_RESCUED], (double)c_res);
-        if (c_exc) atomicAdd(&counters[LC_N_EXCLUDED], (double)c_exc);
+        s_new[threadIdx.x >> 6] = c_new;
+        s_res[threadIdx.x >> 6] = c_res;
         s_wave[threadIdx.x >> 6] = c_exc;
     }
-    if (!minlist) return;
-    // The members of the new exclusion set as a list (engine 2's minority-driven locus tally): ONE atomic per block
-    // reserves the block's slots (per-wave atomics on the one counter serialise: 0.17 ms at 1M cells), then a second
-    // walk over the span (L2-hot) fills them.  The list's order depends on the block order only through the bases, and
-    // only order-independent integer tallies are derived from it.
     __syncthreads();
+    // The members of the new exclusion set as a list (engine 2's minority-driven locus tally): ONE atomic per block
+    // reserves the block's slots, then a second walk over the span (L2-hot) fills them.  The list's order depends on
+    // the block order only through the bases, and only order-independent integer tallies are derived from it.
     if (threadIdx.x == 0) {
-        uint32_t tot = 0;
+        uint32_t tot = 0, t_new = 0, t_res = 0;
         for (int w = 0; w < FLAG_THREADS / 64; w++) {
             const uint32_t x = s_wave[w];
             s_wave[w] = tot;
             tot += x;
+            t_new += s_new[w];
+            t_res += s_res[w];
         }
-        s_base = tot ? atomicAdd(n_min, tot) : 0u;
+        if (t_new) atomicAdd(&counters[LC_N_NEW], (double)t_new);
+        if (t_res) atomicAdd(&counters[LC_N_RESCUED], (double)t_res);
+        if (tot) atomicAdd(&counters[LC_N_EXCLUDED], (double)tot);
+        s_base = (tot && minlist) ? atomicAdd(n_min, tot) : 0u;
     }
+    if (!minlist) return;
     __syncthreads();
     uint32_t pos = s_base + s_wave[threadIdx.x >> 6];
     const uint64_t end_round = beg + (end - beg + 63) / 64 * 64;  // whole waves take part in the ballot

@@ -304,12 +304,30 @@ __device__ __noinline__ double ov_slow_expected(const double *lf, double alpha, 
     return dm_expected_log_pmf(lf, alpha, beta, n);
 }
 
+// ln sum_k pmf(k)^2 (stats.rs:8-22) for 4 <= n <= OV_NE by the pmf ratio recurrence of dm_expected_log_pmf, with pmf(0) built
+// from per-factor ratios (each in (0, 1]: no overflow of long products at these n)
+__device__ __forceinline__ double ov_expected_rec(double alpha, double beta, uint32_t n)
+{
+    const double ab = alpha + beta;
+    double p = 1.0;
+    for (uint32_t j = 0; j < n; ++j) p *= (beta + (double)j) / (ab + (double)j);
+    double s = p * p;
+    for (uint32_t k = 0; k < n; ++k) {
+        p *= ((double)(n - k) * (alpha + (double)k)) / ((double)(k + 1) * (beta + (double)(n - k - 1)));
+        s += p * p;
+    }
+    return log(s);
+}
+
 // Per-locus overflow table (OV_ROW doubles): [0..17] LA[i] = sum_{m<i} ln(alpha+m), [18..35] LB, [36..53] LAB,
-// [64..] E(n) for n = 4..OV_NE (ln sum_k pmf(k)^2, stats.rs:8-22).  32 lanes per locus: lane i < 17 takes the three
-// logs of index i, a width-32 shuffle scan turns them into the cumulative sums.
+// [64..] E(n) for n = 4..OV_NE.  32 lanes per locus: lane i < 17 takes the three logs of index i, a width-32 shuffle
+// scan turns them into the cumulative sums; lane i < 14 also takes E(4 + i) when an overflow entry of the locus has that
+// total (nmask: static), so that one launch serves the whole table.
 #define OV_ROW 128
 #define OV_EOFF 64
-__global__ __launch_bounds__(256) void k_ovf_tables(uint64_t L, const double2 *__restrict__ ab, double *__restrict__ otab)
+template <bool EXPECTED>
+__global__ __launch_bounds__(256) void k_ovf_tables(uint64_t L, const double2 *__restrict__ ab,
+                                                    const uint32_t *__restrict__ nmask, double *__restrict__ otab)
 {
     const uint64_t l = ((uint64_t)blockIdx.x * 256 + threadIdx.x) >> 5;
     const int i = threadIdx.x & 31;
@@ -339,31 +357,15 @@ __global__ __launch_bounds__(256) void k_ovf_tables(uint64_t L, const double2 *_
         row[OV_NT + i] = ib - tb;
         row[2 * OV_NT + i] = ic - tc;
     }
-}
-
-// E(n), n = 4..17, one thread per (locus, n): ln sum_k pmf(k)^2 from the cumulative tables written above
-__global__ void k_ovf_tables_e(uint64_t L, const double *__restrict__ lf, const uint32_t *__restrict__ nmask,
-                               double *__restrict__ otab)
-{
-    const uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const uint64_t l = idx / (OV_NE - 3);
-    if (l >= L) return;
-    const int n = 4 + (int)(idx % (OV_NE - 3));
-    if (!((nmask[l] >> (n - 4)) & 1u)) return;  // no overflow entry of this locus has this n: E(n) is never read
-    double *row = otab + l * OV_ROW;
-    if (row[0] < 0.0) return;  // masked locus
-    const double labn = row[2 * OV_NT + n];
-    double ssum = 0.0;  // pmf(k) >= 1/(n+1) for the modal k: no underflow of the sum
-    for (int k = 0; k <= n; k++)
-        ssum += exp(2.0 * (dm_ln_choose(lf, (uint32_t)k, (uint32_t)(n - k)) + (row[k] + row[OV_NT + n - k] - labn)));
-    row[OV_EOFF + (n - 4)] = log(ssum);
+    if (EXPECTED && i <= OV_NE - 4 && ((nmask[l] >> i) & 1u)) row[OV_EOFF + i] = ov_expected_rec(p.x, p.y, 4u + (uint32_t)i);
 }
 
 template <bool EXPECTED>
 __global__ __launch_bounds__(256) void k_ovf_values(uint64_t L, const uint64_t *__restrict__ ovc_ptr,
                                                     const uint64_t *__restrict__ ovc_ent,
                                                     const double2 *__restrict__ ab, const double *__restrict__ lf_g,
-                                                    const double *__restrict__ otab, double2 *__restrict__ val)
+                                                    const double *__restrict__ otab, double2 *__restrict__ val,
+                                                    double *__restrict__ lp_only /*may be null: the locus pass' copy*/)
 {
     __shared__ double lf[LF_TABLE_N];
     for (int i = threadIdx.x; i < LF_TABLE_N; i += 256) lf[i] = lf_g[i];
@@ -375,7 +377,10 @@ __global__ __launch_bounds__(256) void k_ovf_values(uint64_t L, const uint64_t *
         if (beg == end) continue;
         const double2 p = ab[l];
         if (!(p.x >= 0.0)) {  // masked locus: no PMFData (main.rs:556)
-            for (uint64_t i = beg + lane; i < end; i += 64) val[i] = make_double2(0.0, 0.0);
+            for (uint64_t i = beg + lane; i < end; i += 64) {
+                val[i] = make_double2(0.0, 0.0);
+                if (lp_only) lp_only[i] = 0.0;
+            }
             continue;
         }
         const double tv = otab[l * OV_ROW + lane];              // cumulative log tables, one value per lane
@@ -397,6 +402,7 @@ __global__ __launch_bounds__(256) void k_ovf_values(uint64_t L, const uint64_t *
             else lp = ov_slow_log_pmf(lf, p.x, p.y, a, r);
             if (EXPECTED && n != 0) ee = (n >= 4 && n <= (uint32_t)OV_NE) ? ex : ov_slow_expected(lf, p.x, p.y, n);
             val[i] = make_double2(lp, ee);
+            if (lp_only) lp_only[i] = lp;  // the locus pass streams this: half the bytes of the pairs
         }
     }
 }
@@ -671,8 +677,9 @@ __global__ __launch_bounds__(LS_THREADS) void k_locus_stats2(uint64_t L, uint32_
 // ---------------------------------------------------------------------------------------------------------
 #define LR_LOCI 1024     // loci per range: the LDS histogram is LR_LOCI x 16 codes x u32 = 64 KB
 #define LR_SUB 4         // subsets of the exclusion set (partial planes)
-#define LR_THREADS 1024
+#define LR_THREADS 512   // two workgroups per CU at 128 VGPRs: 16 entry loads per lane stay in flight
 #define LR_GROUP 16      // lanes per (cell, range) segment: ~10 entries at 1 % density
+#define LR_ROW (LR_LOCI + 1)
 
 // roff[cell][r] = number of the row's entries with locus < r * LR_LOCI, r = 0..R (row sorted by locus).  Wave per row.
 __global__ __launch_bounds__(256) void k_range_offsets(uint64_t n_rows, uint32_t R, const uint64_t *__restrict__ csr_ptr,
@@ -695,17 +702,57 @@ __global__ __launch_bounds__(256) void k_range_offsets(uint64_t n_rows, uint32_t
     }
 }
 
+// The excluded cells' offset rows, gathered and transposed: mroff[r][k] for the k-th cell of minlist, mbeg[k] = start of its
+// row.  k_minority_ranges then reads its range's offsets as contiguous runs instead of one 64-byte line per (cell, range)
+// out of the big per-cell table (measured: those line fetches were a third of that kernel's traffic).
+#define LT_CELLS 64
+__global__ __launch_bounds__(256) void k_minority_offsets(int locus_mode, uint64_t nloc, uint32_t R, uint64_t mstride,
+                                                          const uint32_t *__restrict__ n_min_p,
+                                                          const uint32_t *__restrict__ minlist,
+                                                          const uint64_t *__restrict__ csr_ptr,
+                                                          const uint32_t *__restrict__ roff, uint32_t *__restrict__ mroff,
+                                                          uint64_t *__restrict__ mbeg)
+{
+    const uint32_t n_min = *n_min_p;
+    if (!locus_by_minority(locus_mode, n_min, nloc)) return;
+    const uint32_t k0 = blockIdx.x * LT_CELLS;
+    if (k0 >= n_min) return;
+    extern __shared__ uint32_t s_t[];  // [LT_CELLS][row], row odd: the column read below strides by it
+    __shared__ uint32_t s_cell[LT_CELLS];
+    const uint32_t row = (R + 1) | 1u, nk = min((uint32_t)LT_CELLS, n_min - k0);
+    if (threadIdx.x < nk) {
+        const uint32_t cell = minlist[k0 + threadIdx.x];
+        s_cell[threadIdx.x] = cell;
+        mbeg[k0 + threadIdx.x] = csr_ptr[cell];
+    }
+    __syncthreads();
+    // every cell's offsets are one contiguous run of R + 1 words: all threads stride over the (cell, range) pairs, so
+    // that many independent loads are in flight
+    const uint32_t tot = nk * (R + 1);
+#pragma unroll 8
+    for (uint32_t i = threadIdx.x; i < tot; i += 256) {
+        const uint32_t c = i / (R + 1), r = i - c * (R + 1);
+        s_t[c * row + r] = roff[(uint64_t)s_cell[c] * (R + 1) + r];
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < (R + 1) * LT_CELLS; i += 256) {
+        const uint32_t r = i / LT_CELLS, c = i % LT_CELLS;
+        if (c < nk) mroff[(uint64_t)r * mstride + k0 + c] = s_t[c * row + r];
+    }
+}
+
 __global__ __launch_bounds__(LR_THREADS) void k_minority_ranges(int locus_mode, uint64_t nloc, uint64_t L, uint32_t R,
-                                                               const uint32_t *__restrict__ n_min_p,
-                                                               const uint32_t *__restrict__ minlist,
-                                                               const uint64_t *__restrict__ csr_ptr,
-                                                               const uint32_t *__restrict__ roff,
+                                                               uint64_t mstride, const uint32_t *__restrict__ n_min_p,
+                                                               const uint32_t *__restrict__ mroff,
+                                                               const uint64_t *__restrict__ mbeg,
                                                                const uint64_t *__restrict__ csr_ent,
                                                                uint32_t *__restrict__ hist_min /*[LR_SUB][L][16]*/)
 {
     const uint32_t n_min = *n_min_p;
     if (!locus_by_minority(locus_mode, n_min, nloc)) return;
-    __shared__ uint32_t s_hist[LR_LOCI * 16];
+    // code-major with a padded row: the bank of a counter follows the locus (spread out), not the code (most entries
+    // are single reads: codes 0 and 1), and the transposing read at the end is conflict-poor as well
+    __shared__ uint32_t s_hist[16 * LR_ROW];
     __shared__ uint64_t s_beg[LR_THREADS];
     __shared__ uint32_t s_len[LR_THREADS];
     const uint32_t tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
@@ -713,53 +760,57 @@ __global__ __launch_bounds__(LR_THREADS) void k_minority_ranges(int locus_mode, 
     const uint32_t per = (n_min + LR_SUB - 1) / LR_SUB;
     const uint32_t k0 = min(n_min, sub * per), k1 = min(n_min, k0 + per);
     const uint32_t l0 = r * LR_LOCI;
-    for (uint32_t i = tid; i < LR_LOCI * 16; i += LR_THREADS) s_hist[i] = 0;
+    for (uint32_t i = tid; i < 16 * LR_ROW; i += LR_THREADS) s_hist[i] = 0;
     const uint32_t grp = lane / LR_GROUP, gl = lane % LR_GROUP;
+    // one excluded cell per thread: where its entries of this range start, and how many there are (requested one batch
+    // ahead, so the loads fly during the batch before)
+    uint64_t p_b = 0;
+    uint32_t p_n = 0;
+#define LR_PREFETCH(KB)                                                                                          \
+    do {                                                                                                         \
+        const uint32_t k__ = (KB) + tid;                                                                         \
+        p_b = 0; p_n = 0;                                                                                        \
+        if (k__ < k1) {                                                                                          \
+            const uint32_t o0__ = mroff[(uint64_t)r * mstride + k__], o1__ = mroff[(uint64_t)(r + 1) * mstride + k__]; \
+            p_b = mbeg[k__] + o0__;                                                                              \
+            p_n = o1__ - o0__;                                                                                   \
+        }                                                                                                        \
+    } while (0)
+    LR_PREFETCH(k0);
     for (uint32_t kb = k0; kb < k1; kb += LR_THREADS) {
-        // 1. one excluded cell per thread: where its entries of this range start, and how many there are
-        {
-            const uint32_t k = kb + tid;
-            uint64_t b = 0;
-            uint32_t n = 0;
-            if (k < k1) {
-                const uint32_t cell = minlist[k];
-                const uint32_t *o = roff + (uint64_t)cell * (R + 1) + r;
-                const uint32_t o0 = o[0], o1 = o[1];
-                b = csr_ptr[cell] + o0;
-                n = o1 - o0;
-            }
-            s_beg[tid] = b;
-            s_len[tid] = n;
-        }
+        s_beg[tid] = p_b;
+        s_len[tid] = p_n;
         __syncthreads();  // (also: the histogram is zeroed)
-        // 2. a wave takes 64 of the segments, LR_GROUP lanes per segment, four segment quads per trip so that four
-        //    loads per lane are in flight; the rare segment longer than LR_GROUP finishes in a loop
-        for (uint32_t q0 = 0; q0 < 64 / (64 / LR_GROUP); q0 += 4) {
-            uint64_t e[4], sb[4];
-            uint32_t sn[4];
+        LR_PREFETCH(kb + LR_THREADS);
+        // a wave takes 64 of the segments, LR_GROUP lanes per segment: the first LR_GROUP entries of all of them are
+        // requested back to back (16 loads per lane in flight), then counted; the rare longer segment finishes in a loop
+        constexpr int NQ = 64 / (64 / LR_GROUP);
+        uint64_t e[NQ];
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const uint32_t seg = wv * 64 + (q0 + u) * (64 / LR_GROUP) + grp;
-                sb[u] = s_beg[seg];
-                sn[u] = s_len[seg];
-                e[u] = gl < sn[u] ? csr_ent[sb[u] + gl] : 0;  // 0: alt + ref == 0, not regular
-            }
+        for (int u = 0; u < NQ; u++) {
+            const uint32_t seg = wv * 64 + u * (64 / LR_GROUP) + grp;
+            e[u] = gl < s_len[seg] ? csr_ent[s_beg[seg] + gl] : 0;  // 0: alt + ref == 0, not regular
+        }
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                if (ent_regular(e[u])) atomicAdd(&s_hist[(ENT_IDX(e[u]) - l0) * 16 + ent_code(e[u])], 1u);
-                for (uint32_t j = gl + LR_GROUP; j < sn[u]; j += LR_GROUP) {
-                    const uint64_t x = csr_ent[sb[u] + j];
-                    if (ent_regular(x)) atomicAdd(&s_hist[(ENT_IDX(x) - l0) * 16 + ent_code(x)], 1u);
-                }
+        for (int u = 0; u < NQ; u++)
+            if (ent_regular(e[u])) atomicAdd(&s_hist[ent_code(e[u]) * LR_ROW + (ENT_IDX(e[u]) - l0)], 1u);
+        for (int u = 0; u < NQ; u++) {
+            const uint32_t seg = wv * 64 + u * (64 / LR_GROUP) + grp;
+            const uint32_t sn = s_len[seg];
+            const uint64_t sb = s_beg[seg];
+            for (uint32_t j = gl + LR_GROUP; j < sn; j += LR_GROUP) {
+                const uint64_t x = csr_ent[sb + j];
+                if (ent_regular(x)) atomicAdd(&s_hist[ent_code(x) * LR_ROW + (ENT_IDX(x) - l0)], 1u);
             }
         }
         __syncthreads();  // segments consumed before the next batch overwrites them
     }
+#undef LR_PREFETCH
     __syncthreads();
     // 3. this subset's plane of the range
     const uint64_t nl = min((uint64_t)LR_LOCI, L - l0);
     uint32_t *dst = hist_min + ((uint64_t)sub * L + l0) * 16;
-    for (uint32_t i = tid; i < nl * 16; i += LR_THREADS) dst[i] = s_hist[i];
+    for (uint32_t i = tid; i < nl * 16; i += LR_THREADS) dst[i] = s_hist[(i & 15u) * LR_ROW + (i >> 4)];
 }
 
 // Outputs of the locus pass from the minority counts (both forms end here, so they agree to the bit).  16 lanes per
@@ -783,7 +834,7 @@ __global__ __launch_bounds__(256) void k_locus_finalize(uint64_t L, int locus_mo
                                                         const uint8_t *__restrict__ mask,
                                                         const uint64_t *__restrict__ ovc_ptr /*null: no overflow*/,
                                                         const uint64_t *__restrict__ ovc_ent,
-                                                        const double2 *__restrict__ ovf_val, double *__restrict__ out)
+                                                        const double *__restrict__ ovf_lp, double *__restrict__ out)
 {
     const int nplanes = locus_by_minority(locus_mode, *n_min_p, nloc) ? LR_SUB : 1;
     const uint32_t j = threadIdx.x % LF_LANES;
@@ -820,7 +871,7 @@ __global__ __launch_bounds__(256) void k_locus_finalize(uint64_t L, int locus_mo
             const uint64_t i = i0 + (uint64_t)u * LF_LANES;
             const bool ok = i < oend;
             en[u] = ok ? ovc_ent[i] : ~0ull;
-            lp[u] = ok ? ovf_val[i].x : 0.0;
+            lp[u] = ok ? ovf_lp[i] : 0.0;
         }
 #pragma unroll
         for (int u = 0; u < 4; u++) w[u] = en[u] != ~0ull ? flag_bits[ENT_IDX(en[u]) >> 5] : 0u;
@@ -1112,7 +1163,8 @@ void tiled_free(cellector_ctx *c)
     dev_free(c->c4_ptr); dev_free(c->c4_ent); dev_free(c->ovc_ptr); dev_free(c->ovc_ent);
     dev_free(c->hist_all); dev_free(c->tab); dev_free(c->part); dev_free(c->ab3);
     dev_free(c->masked_cnt); dev_free(c->flag_bits); dev_free(c->ovf_perm); dev_free(c->ovf_val); dev_free(c->ovf_tab);
-    dev_free(c->ovf_sum); dev_free(c->ovf_nmask); dev_free(c->minlist); dev_free(c->hist_min); dev_free(c->roff);
+    dev_free(c->ovf_sum); dev_free(c->ovf_lp); dev_free(c->ovf_nmask); dev_free(c->minlist); dev_free(c->hist_min); dev_free(c->roff); dev_free(c->mroff); dev_free(c->mbeg);
+    c->mroff_cap = 0;
     c->tiled_ready = false;
     c->ovf_n = 0; c->n_masked_loci = 0;
 }
@@ -1217,6 +1269,7 @@ cellector_status tiled_build(cellector_ctx *c)
     CHK(dev_alloc(c, &c->ovf_perm, c->ovf_n));
     CHK(dev_alloc(c, &c->ovf_val, 3 * c->ovf_n));
     CHK(dev_alloc(c, &c->ovf_sum, 3 * 2 * nloc));
+    CHK(dev_alloc(c, &c->ovf_lp, c->ovf_n));
     CHK(dev_alloc(c, &c->ovf_tab, L * OV_ROW));
     CHK(dev_alloc(c, &c->ovf_nmask, L));
     if (L && c->ovf_n) {
@@ -1260,19 +1313,17 @@ static void launch_overflow_pass(cellector_ctx *c, hipStream_t st, const double2
 {
     double2 *val = c->ovf_val + (uint64_t)set * c->ovf_n;
     double *o_ll = c->ovf_sum + (uint64_t)set * 2 * c->nloc, *o_ell = o_ll + c->nloc;
-    hipLaunchKernelGGL(k_ovf_tables, dim3(gcap(c->L * 32, 256, 0x7fffffffu)), dim3(256), 0, st, c->L, ab, c->ovf_tab);
+    const unsigned tg = gcap(c->L * 32, 256, 0x7fffffffu), vg = gcap(c->L, 4, 4096), sg = gcap(c->nloc, 256, 0x7fffffffu);
     if (expected) {
-        hipLaunchKernelGGL(k_ovf_tables_e, dim3(gcap(c->L * (OV_NE - 3), 256, 0x7fffffffu)), dim3(256), 0, st, c->L, c->lf,
-                           c->ovf_nmask, c->ovf_tab);
-        hipLaunchKernelGGL(k_ovf_values<true>, dim3(gcap(c->L, 4, 4096)), dim3(256), 0, st, c->L, c->ovc_ptr, c->ovc_ent, ab, c->lf,
-                           c->ovf_tab, val);
-        hipLaunchKernelGGL(k_ovf_cell_sums<true>, dim3(gcap(c->nloc, 256, 0x7fffffffu)), dim3(256), 0, st, c->nloc, c->ovf_ptr,
-                           c->ovf_perm, val, o_ll, o_ell);
+        hipLaunchKernelGGL(k_ovf_tables<true>, dim3(tg), dim3(256), 0, st, c->L, ab, c->ovf_nmask, c->ovf_tab);
+        hipLaunchKernelGGL(k_ovf_values<true>, dim3(vg), dim3(256), 0, st, c->L, c->ovc_ptr, c->ovc_ent, ab, c->lf, c->ovf_tab, val,
+                           set == 0 ? c->ovf_lp : (double *)nullptr);
+        hipLaunchKernelGGL(k_ovf_cell_sums<true>, dim3(sg), dim3(256), 0, st, c->nloc, c->ovf_ptr, c->ovf_perm, val, o_ll, o_ell);
     } else {
-        hipLaunchKernelGGL(k_ovf_values<false>, dim3(gcap(c->L, 4, 4096)), dim3(256), 0, st, c->L, c->ovc_ptr, c->ovc_ent, ab, c->lf,
-                           c->ovf_tab, val);
-        hipLaunchKernelGGL(k_ovf_cell_sums<false>, dim3(gcap(c->nloc, 256, 0x7fffffffu)), dim3(256), 0, st, c->nloc, c->ovf_ptr,
-                           c->ovf_perm, val, o_ll, o_ell);
+        hipLaunchKernelGGL(k_ovf_tables<false>, dim3(tg), dim3(256), 0, st, c->L, ab, c->ovf_nmask, c->ovf_tab);
+        hipLaunchKernelGGL(k_ovf_values<false>, dim3(vg), dim3(256), 0, st, c->L, c->ovc_ptr, c->ovc_ent, ab, c->lf, c->ovf_tab, val,
+                           set == 0 ? c->ovf_lp : (double *)nullptr);
+        hipLaunchKernelGGL(k_ovf_cell_sums<false>, dim3(sg), dim3(256), 0, st, c->nloc, c->ovf_ptr, c->ovf_perm, val, o_ll, o_ell);
     }
 }
 
@@ -1396,13 +1447,28 @@ cellector_status tiled_locus_pass(cellector_ctx *c)
         HIPCHK(c, hipMemsetAsync(c->hist_min, 0, (uint64_t)LR_SUB * c->L * 16 * sizeof(uint32_t), c->stream));
     if (c->locus_mode != 1 && c->nloc) {
         const uint32_t R = (uint32_t)((c->L + LR_LOCI - 1) / LR_LOCI);
+        // capacity of the transposed offsets: the largest exclusion set the automatic choice hands to this form; the
+        // forced form (tests, ablations) may need all cells
+        const uint64_t want = c->locus_mode == 2 ? c->nloc : c->nloc * LM_NUM / LM_DEN + LT_CELLS;
+        if (c->mroff_cap < want) {
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            dev_free(c->mroff); dev_free(c->mbeg);
+            c->mroff_cap = (want + 63) & ~63ull;
+            CHK(dev_alloc(c, &c->mroff, (uint64_t)(R + 1) * c->mroff_cap));
+            CHK(dev_alloc(c, &c->mbeg, c->mroff_cap));
+        }
+        const size_t lds_t = (size_t)LT_CELLS * (R + 2) * sizeof(uint32_t);
+        if (lds_t > 64 * 1024)
+            HIPCHK(c, hipFuncSetAttribute((const void *)k_minority_offsets, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_t));
+        hipLaunchKernelGGL(k_minority_offsets, dim3(gcap(want, LT_CELLS, 0x7fffffffu)), dim3(256), lds_t, c->stream, c->locus_mode,
+                           c->nloc, R, c->mroff_cap, c->d_counters + DC_N_MIN, c->minlist, c->csr_ptr, c->roff, c->mroff, c->mbeg);
         hipLaunchKernelGGL(k_minority_ranges, dim3(R * LR_SUB), dim3(LR_THREADS), 0, c->stream, c->locus_mode, c->nloc, c->L, R,
-                           c->d_counters + DC_N_MIN, c->minlist, c->csr_ptr, c->roff, c->csr_ent, c->hist_min);
+                           c->mroff_cap, c->d_counters + DC_N_MIN, c->mroff, c->mbeg, c->csr_ent, c->hist_min);
     }
     hipLaunchKernelGGL(k_locus_finalize, dim3(gcap(c->L * LF_LANES, 256, 0x7fffffffu)), dim3(256), 0, c->stream, c->L, c->locus_mode,
                        c->nloc, c->d_counters + DC_N_MIN, c->hist_min, c->flag_bits, c->hist_all, c->tab_em,
                        (uint32_t)c->tab_em_stride, c->mask, c->ovf_n ? c->ovc_ptr : (const uint64_t *)nullptr, c->ovc_ent,
-                       c->ovf_val, c->x_locus);
+                       c->ovf_lp, c->x_locus);
     timer_end(c, CELLECTOR_K_LOCUS_STATS);
     HIPCHK(c, hipGetLastError());
     return CELLECTOR_OK;

@@ -19,6 +19,6 @@ if f:
     rows=list(csv.DictReader(open(f[0])))
     for r in rows:
         n=r["Name"]
-        if any(k in n for k in ("k_tile_ll","k_locus","k_ovf_v","k_ovf_t","k_ovf_c","k_cell_f","k_sel","k_flag","k_build_t","k_alpha","k_pack","k_thr","k_post")):
+        if any(k in n for k in ("k_tile_ll","k_locus","k_minority","k_ovf_v","k_ovf_t","k_ovf_c","k_cell_f","k_sel","k_flag","k_build_t","k_alpha","k_pack","k_thr","k_post")):
             print(f"  {n[:60]:60s} calls={r['Calls']:>4s} avg_us={float(r['AverageNs'])/1e3:9.1f}")
 PY
