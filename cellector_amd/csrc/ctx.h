@@ -121,10 +121,11 @@ struct cellector_ctx {
     uint32_t *flag_bits = nullptr;   // [ceil(nloc/32)] new exclusion set as a bitmask
     uint64_t n_masked_loci = 0;
     uint32_t *minlist = nullptr;     // [nloc] local ids of the cells of the new exclusion set (arbitrary order)
-    uint32_t *hist_min = nullptr;    // [LR_SUB][L][16] regular entries of minority cells per (locus, code), partial planes
+    uint32_t *hist_min = nullptr;    // [lr_sub][L][16] regular entries of minority cells per (locus, code), partial planes
     uint32_t *mroff = nullptr;       // [R+1][mroff_cap] the excluded cells' offset rows, transposed (per iteration)
     uint64_t *mbeg = nullptr;        // [mroff_cap] start of the excluded cells' rows in csr_ent
     uint64_t mroff_cap = 0;
+    uint32_t lr_sub = 1;             // subsets of the exclusion set = partial planes of hist_min
     uint32_t *roff = nullptr;        // [nloc][R+1] offsets of the locus ranges inside each by-cell CSR row
     int locus_mode = 0;              // option "locus_mode": 0 = chosen on the device per iteration, 1 = stream the compact CSC,
                                      // 2 = minority-driven tally over the by-cell CSR

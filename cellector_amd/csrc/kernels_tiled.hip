@@ -549,8 +549,10 @@ __global__ void k_pack_flag_bits(uint64_t n, const uint8_t *__restrict__ flags, 
 // Form of the locus pass, decided on the device from this shard's exclusion-set size (see k_minority_hist below)
 #define LM_NUM 1  // minority-driven when n_min / nloc <= LM_NUM / LM_DEN
 #define LM_DEN 8
-__device__ __forceinline__ bool locus_by_minority(int mode, uint32_t n_min, uint64_t nloc)
+// (n_sub = partial planes of the minority-driven form: its 16-bit LDS counters hold a subset of at most 65535 cells)
+__device__ __forceinline__ bool locus_by_minority(int mode, uint32_t n_min, uint64_t nloc, uint32_t n_sub)
 {
+    if ((uint64_t)n_min > (uint64_t)n_sub * 65535u) return false;
     return mode == 2 || (mode == 0 && (uint64_t)n_min * LM_DEN <= nloc * LM_NUM);
 }
 
@@ -564,9 +566,9 @@ __global__ __launch_bounds__(LS_THREADS) void k_locus_stats2(uint64_t L, uint32_
                                                              const uint32_t *__restrict__ c4_ent,
                                                              const uint32_t *__restrict__ flag_bits,
                                                              uint32_t *__restrict__ hist_min /*plane 0*/, int locus_mode,
-                                                             uint64_t nloc, const uint32_t *__restrict__ n_min)
+                                                             uint64_t nloc, const uint32_t *__restrict__ n_min, uint32_t n_sub)
 {
-    if (locus_by_minority(locus_mode, *n_min, nloc)) return;  // k_minority_ranges counts this iteration
+    if (locus_by_minority(locus_mode, *n_min, nloc, n_sub)) return;  // k_minority_ranges counts this iteration
     extern __shared__ uint32_t s_bits[];
     __shared__ uint32_t s_whist[LS_THREADS / 64][16];
     if (threadIdx.x < (LS_THREADS / 64) * 16) (&s_whist[0][0])[threadIdx.x] = 0;
@@ -668,18 +670,21 @@ __global__ __launch_bounds__(LS_THREADS) void k_locus_stats2(uint64_t L, uint32_
 // small part of the cells (below the lower quartile by construction, a few percent in practice).  So instead of
 // streaming the whole compact CSC past the exclusion bitmask, walk only the by-cell CSR rows of the excluded cells.
 // Global atomics are out (measured: 2.7e10 scattered u32 atomics/s on this chip, 3.7 ms for cfg4's 1e8 entries), so
-// the counting happens in LDS: the loci are cut into ranges of LR_LOCI, a workgroup owns one range and one of LR_SUB
+// the counting happens in LDS: the loci are cut into ranges of LR_LOCI, a workgroup owns one range and one of n_sub
 // subsets of the excluded cells, finds every such cell's entries of its range through a per-(cell, range) offset
 // table built at ingest (roff), counts them into a u32 histogram in LDS (integer atomics: exact, order independent)
-// and writes the histogram out as one of LR_SUB partial planes; k_locus_finalize adds the planes.  The result is
+// and writes the histogram out as one of n_sub partial planes; k_locus_finalize adds the planes.  The result is
 // bit-identical to the streamed form.  Cost: the excluded cells' entries instead of all of them.  The form is chosen
 // on the device from this shard's exclusion-set size (no host round trip); the kernels of the other form return at once.
 // ---------------------------------------------------------------------------------------------------------
-#define LR_LOCI 1024     // loci per range: the LDS histogram is LR_LOCI x 16 codes x u32 = 64 KB
-#define LR_SUB 4         // subsets of the exclusion set (partial planes)
-#define LR_THREADS 512   // two workgroups per CU at 128 VGPRs: 16 entry loads per lane stay in flight
-#define LR_GROUP 16      // lanes per (cell, range) segment: ~10 entries at 1 % density
-#define LR_ROW (LR_LOCI + 1)
+// A (cell, range) segment is a short run inside a long row and memory comes in 128-byte lines, so short segments waste
+// most of what they fetch (measured at 1024 loci per range: 80-byte segments, 2 GB fetched for 0.8 GB of entries, the
+// kernel at the HBM rate).  Hence wide ranges, with 16-bit counters so that the histogram still fits in LDS.
+#define LR_LOCI 4096     // loci per range: the LDS histogram is 14 codes x LR_LOCI x u16 = 112 KB
+#define LR_SUB_MAX 16    // at most this many subsets of the exclusion set (partial planes); chosen per matrix
+#define LR_THREADS 1024  // one workgroup per CU, 128 VGPRs: 16 entry loads per lane stay in flight
+#define LR_GROUP 64      // lanes per (cell, range) segment: ~41 entries at 1 % density (a tail loop would serialise)
+#define LR_ROW (LR_LOCI + 2)  // u16 counters per code row (even: a row starts on a word)
 
 // roff[cell][r] = number of the row's entries with locus < r * LR_LOCI, r = 0..R (row sorted by locus).  Wave per row.
 __global__ __launch_bounds__(256) void k_range_offsets(uint64_t n_rows, uint32_t R, const uint64_t *__restrict__ csr_ptr,
@@ -706,7 +711,7 @@ __global__ __launch_bounds__(256) void k_range_offsets(uint64_t n_rows, uint32_t
 // row.  k_minority_ranges then reads its range's offsets as contiguous runs instead of one 64-byte line per (cell, range)
 // out of the big per-cell table (measured: those line fetches were a third of that kernel's traffic).
 #define LT_CELLS 64
-__global__ __launch_bounds__(256) void k_minority_offsets(int locus_mode, uint64_t nloc, uint32_t R, uint64_t mstride,
+__global__ __launch_bounds__(256) void k_minority_offsets(int locus_mode, uint64_t nloc, uint32_t n_sub, uint32_t R, uint64_t mstride,
                                                           const uint32_t *__restrict__ n_min_p,
                                                           const uint32_t *__restrict__ minlist,
                                                           const uint64_t *__restrict__ csr_ptr,
@@ -714,7 +719,7 @@ __global__ __launch_bounds__(256) void k_minority_offsets(int locus_mode, uint64
                                                           uint64_t *__restrict__ mbeg)
 {
     const uint32_t n_min = *n_min_p;
-    if (!locus_by_minority(locus_mode, n_min, nloc)) return;
+    if (!locus_by_minority(locus_mode, n_min, nloc, n_sub)) return;
     const uint32_t k0 = blockIdx.x * LT_CELLS;
     if (k0 >= n_min) return;
     extern __shared__ uint32_t s_t[];  // [LT_CELLS][row], row odd: the column read below strides by it
@@ -742,26 +747,34 @@ __global__ __launch_bounds__(256) void k_minority_offsets(int locus_mode, uint64
 }
 
 __global__ __launch_bounds__(LR_THREADS) void k_minority_ranges(int locus_mode, uint64_t nloc, uint64_t L, uint32_t R,
-                                                               uint64_t mstride, const uint32_t *__restrict__ n_min_p,
+                                                               uint32_t n_sub, uint64_t mstride,
+                                                               const uint32_t *__restrict__ n_min_p,
                                                                const uint32_t *__restrict__ mroff,
                                                                const uint64_t *__restrict__ mbeg,
                                                                const uint64_t *__restrict__ csr_ent,
-                                                               uint32_t *__restrict__ hist_min /*[LR_SUB][L][16]*/)
+                                                               uint32_t *__restrict__ hist_min /*[n_sub][L][16]*/)
 {
     const uint32_t n_min = *n_min_p;
-    if (!locus_by_minority(locus_mode, n_min, nloc)) return;
-    // code-major with a padded row: the bank of a counter follows the locus (spread out), not the code (most entries
-    // are single reads: codes 0 and 1), and the transposing read at the end is conflict-poor as well
-    __shared__ uint32_t s_hist[16 * LR_ROW];
+    if (!locus_by_minority(locus_mode, n_min, nloc, n_sub)) return;
+    // u16 counters, two per word, code-major: the bank of a counter follows the locus (spread out), not the code (most
+    // entries are single reads: codes 0 and 1).  A subset has at most 65535 cells (locus_by_minority): no carry.
+    __shared__ uint32_t s_hist[T_NCODE * LR_ROW / 2];
     __shared__ uint64_t s_beg[LR_THREADS];
     __shared__ uint32_t s_len[LR_THREADS];
     const uint32_t tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
     const uint32_t r = blockIdx.x % R, sub = blockIdx.x / R;
-    const uint32_t per = (n_min + LR_SUB - 1) / LR_SUB;
+    const uint32_t per = (n_min + n_sub - 1) / n_sub;
     const uint32_t k0 = min(n_min, sub * per), k1 = min(n_min, k0 + per);
     const uint32_t l0 = r * LR_LOCI;
-    for (uint32_t i = tid; i < 16 * LR_ROW; i += LR_THREADS) s_hist[i] = 0;
+    for (uint32_t i = tid; i < T_NCODE * LR_ROW / 2; i += LR_THREADS) s_hist[i] = 0;
     const uint32_t grp = lane / LR_GROUP, gl = lane % LR_GROUP;
+#define LR_COUNT(E)                                                                                              \
+    do {                                                                                                         \
+        if (ent_regular(E)) {                                                                                    \
+            const uint32_t idx__ = ent_code(E) * LR_ROW + (ENT_IDX(E) - l0);                                     \
+            atomicAdd(&s_hist[idx__ >> 1], 1u << ((idx__ & 1u) * 16u));                                          \
+        }                                                                                                        \
+    } while (0)
     // one excluded cell per thread: where its entries of this range start, and how many there are (requested one batch
     // ahead, so the loads fly during the batch before)
     uint64_t p_b = 0;
@@ -782,35 +795,41 @@ __global__ __launch_bounds__(LR_THREADS) void k_minority_ranges(int locus_mode, 
         s_len[tid] = p_n;
         __syncthreads();  // (also: the histogram is zeroed)
         LR_PREFETCH(kb + LR_THREADS);
-        // a wave takes 64 of the segments, LR_GROUP lanes per segment: the first LR_GROUP entries of all of them are
-        // requested back to back (16 loads per lane in flight), then counted; the rare longer segment finishes in a loop
-        constexpr int NQ = 64 / (64 / LR_GROUP);
-        uint64_t e[NQ];
+        // a wave takes 64 of the segments, LR_GROUP lanes per segment; per trip the first LR_GROUP entries of 32 of them
+        // are requested back to back (16 loads per lane in flight), then counted; longer segments finish in a loop
+        constexpr int SPW = 64 / LR_GROUP;  // segments per wave load
+        constexpr int NQ = 16;
+        for (uint32_t q0 = 0; q0 < 64 / SPW; q0 += NQ) {
+            uint64_t e[NQ];
 #pragma unroll
-        for (int u = 0; u < NQ; u++) {
-            const uint32_t seg = wv * 64 + u * (64 / LR_GROUP) + grp;
-            e[u] = gl < s_len[seg] ? csr_ent[s_beg[seg] + gl] : 0;  // 0: alt + ref == 0, not regular
-        }
+            for (int u = 0; u < NQ; u++) {
+                const uint32_t seg = wv * 64 + (q0 + u) * SPW + grp;
+                e[u] = gl < s_len[seg] ? csr_ent[s_beg[seg] + gl] : 0;  // 0: alt + ref == 0, not regular
+            }
 #pragma unroll
-        for (int u = 0; u < NQ; u++)
-            if (ent_regular(e[u])) atomicAdd(&s_hist[ent_code(e[u]) * LR_ROW + (ENT_IDX(e[u]) - l0)], 1u);
-        for (int u = 0; u < NQ; u++) {
-            const uint32_t seg = wv * 64 + u * (64 / LR_GROUP) + grp;
-            const uint32_t sn = s_len[seg];
-            const uint64_t sb = s_beg[seg];
-            for (uint32_t j = gl + LR_GROUP; j < sn; j += LR_GROUP) {
-                const uint64_t x = csr_ent[sb + j];
-                if (ent_regular(x)) atomicAdd(&s_hist[ent_code(x) * LR_ROW + (ENT_IDX(x) - l0)], 1u);
+            for (int u = 0; u < NQ; u++) LR_COUNT(e[u]);
+            for (int u = 0; u < NQ; u++) {
+                const uint32_t seg = wv * 64 + (q0 + u) * SPW + grp;
+                const uint32_t sn = s_len[seg];
+                const uint64_t sb = s_beg[seg];
+                for (uint32_t j = gl + LR_GROUP; j < sn; j += LR_GROUP) {
+                    const uint64_t x = csr_ent[sb + j];
+                    LR_COUNT(x);
+                }
             }
         }
         __syncthreads();  // segments consumed before the next batch overwrites them
     }
 #undef LR_PREFETCH
+#undef LR_COUNT
     __syncthreads();
-    // 3. this subset's plane of the range
+    // this subset's plane of the range, as [locus][16] u32 (codes 14, 15: zero)
     const uint64_t nl = min((uint64_t)LR_LOCI, L - l0);
     uint32_t *dst = hist_min + ((uint64_t)sub * L + l0) * 16;
-    for (uint32_t i = tid; i < nl * 16; i += LR_THREADS) dst[i] = s_hist[(i & 15u) * LR_ROW + (i >> 4)];
+    for (uint32_t i = tid; i < nl * 16; i += LR_THREADS) {
+        const uint32_t code = i & 15u, idx = code * LR_ROW + (i >> 4);
+        dst[i] = code < (uint32_t)T_NCODE ? (s_hist[idx >> 1] >> ((idx & 1u) * 16u)) & 0xffffu : 0u;
+    }
 }
 
 // Outputs of the locus pass from the minority counts (both forms end here, so they agree to the bit).  16 lanes per
@@ -825,7 +844,7 @@ __device__ __forceinline__ T group16_sum(T v)
     for (int m = LF_LANES / 2; m > 0; m >>= 1) v += __shfl_xor(v, m, LF_LANES);
     return v;
 }
-__global__ __launch_bounds__(256) void k_locus_finalize(uint64_t L, int locus_mode, uint64_t nloc,
+__global__ __launch_bounds__(256) void k_locus_finalize(uint64_t L, int locus_mode, uint64_t nloc, uint32_t n_sub,
                                                         const uint32_t *__restrict__ n_min_p,
                                                         const uint32_t *__restrict__ hist_min,
                                                         const uint32_t *__restrict__ flag_bits,
@@ -836,7 +855,7 @@ __global__ __launch_bounds__(256) void k_locus_finalize(uint64_t L, int locus_mo
                                                         const uint64_t *__restrict__ ovc_ent,
                                                         const double *__restrict__ ovf_lp, double *__restrict__ out)
 {
-    const int nplanes = locus_by_minority(locus_mode, *n_min_p, nloc) ? LR_SUB : 1;
+    const int nplanes = locus_by_minority(locus_mode, *n_min_p, nloc, n_sub) ? (int)n_sub : 1;
     const uint32_t j = threadIdx.x % LF_LANES;
     const uint64_t l_raw = ((uint64_t)blockIdx.x * 256 + threadIdx.x) / LF_LANES;
     const bool in = l_raw < L;
@@ -1291,9 +1310,16 @@ cellector_status tiled_build(cellector_ctx *c)
     CHK(dev_alloc(c, &c->masked_cnt, nloc));
     CHK(dev_alloc(c, &c->flag_bits, (nloc + 31) / 32 + 1));
     CHK(dev_alloc(c, &c->minlist, nloc));
-    CHK(dev_alloc(c, &c->hist_min, (uint64_t)LR_SUB * L * 16));
     {
+        // subsets of the exclusion set: enough (range, subset) workgroups to fill the chip once
+        int ncu = 256;
+        (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, c->device);
         const uint32_t R = (uint32_t)((L + LR_LOCI - 1) / LR_LOCI);
+        uint32_t sub = R ? (uint32_t)ncu / R : 1;  // one workgroup per CU (LDS): at most one round of them
+        if (sub < 1) sub = 1;
+        if (sub > LR_SUB_MAX) sub = LR_SUB_MAX;
+        c->lr_sub = sub;
+        CHK(dev_alloc(c, &c->hist_min, (uint64_t)sub * L * 16));
         CHK(dev_alloc(c, &c->roff, nloc * (R + 1)));
         if (nloc)
             hipLaunchKernelGGL(k_range_offsets, dim3(gcap(nloc, 4)), dim3(256), 0, c->stream, nloc, R, c->csr_ptr, c->csr_ent,
@@ -1425,7 +1451,7 @@ cellector_status tiled_locus_pass(cellector_ctx *c)
     if (grid > need) grid = (unsigned)(need ? need : 1);
 #define LAUNCH_LS(INLDS, EBV, GRID, LDSB)                                                                              \
     hipLaunchKernelGGL((k_locus_stats2<INLDS, EBV>), dim3(GRID), dim3(LS_THREADS), LDSB, c->stream, c->L, words, c->c4_ptr, \
-                       c->c4_ent, c->flag_bits, c->hist_min, c->locus_mode, c->nloc, c->d_counters + DC_N_MIN)
+                       c->c4_ent, c->flag_bits, c->hist_min, c->locus_mode, c->nloc, c->d_counters + DC_N_MIN, c->lr_sub)
     if (c->locus_mode == 2) {
         // minority-driven form forced: nothing to stream
     } else if (lds <= 128 * 1024) {
@@ -1444,7 +1470,7 @@ cellector_status tiled_locus_pass(cellector_ctx *c)
     }
 #undef LAUNCH_LS
     if (c->nloc == 0)  // an empty shard: no kernel fills the planes
-        HIPCHK(c, hipMemsetAsync(c->hist_min, 0, (uint64_t)LR_SUB * c->L * 16 * sizeof(uint32_t), c->stream));
+        HIPCHK(c, hipMemsetAsync(c->hist_min, 0, (uint64_t)c->lr_sub * c->L * 16 * sizeof(uint32_t), c->stream));
     if (c->locus_mode != 1 && c->nloc) {
         const uint32_t R = (uint32_t)((c->L + LR_LOCI - 1) / LR_LOCI);
         // capacity of the transposed offsets: the largest exclusion set the automatic choice hands to this form; the
@@ -1461,12 +1487,12 @@ cellector_status tiled_locus_pass(cellector_ctx *c)
         if (lds_t > 64 * 1024)
             HIPCHK(c, hipFuncSetAttribute((const void *)k_minority_offsets, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_t));
         hipLaunchKernelGGL(k_minority_offsets, dim3(gcap(want, LT_CELLS, 0x7fffffffu)), dim3(256), lds_t, c->stream, c->locus_mode,
-                           c->nloc, R, c->mroff_cap, c->d_counters + DC_N_MIN, c->minlist, c->csr_ptr, c->roff, c->mroff, c->mbeg);
-        hipLaunchKernelGGL(k_minority_ranges, dim3(R * LR_SUB), dim3(LR_THREADS), 0, c->stream, c->locus_mode, c->nloc, c->L, R,
-                           c->mroff_cap, c->d_counters + DC_N_MIN, c->mroff, c->mbeg, c->csr_ent, c->hist_min);
+                           c->nloc, c->lr_sub, R, c->mroff_cap, c->d_counters + DC_N_MIN, c->minlist, c->csr_ptr, c->roff, c->mroff, c->mbeg);
+        hipLaunchKernelGGL(k_minority_ranges, dim3(R * c->lr_sub), dim3(LR_THREADS), 0, c->stream, c->locus_mode, c->nloc, c->L, R,
+                           c->lr_sub, c->mroff_cap, c->d_counters + DC_N_MIN, c->mroff, c->mbeg, c->csr_ent, c->hist_min);
     }
     hipLaunchKernelGGL(k_locus_finalize, dim3(gcap(c->L * LF_LANES, 256, 0x7fffffffu)), dim3(256), 0, c->stream, c->L, c->locus_mode,
-                       c->nloc, c->d_counters + DC_N_MIN, c->hist_min, c->flag_bits, c->hist_all, c->tab_em,
+                       c->nloc, c->lr_sub, c->d_counters + DC_N_MIN, c->hist_min, c->flag_bits, c->hist_all, c->tab_em,
                        (uint32_t)c->tab_em_stride, c->mask, c->ovf_n ? c->ovc_ptr : (const uint64_t *)nullptr, c->ovc_ent,
                        c->ovf_lp, c->x_locus);
     timer_end(c, CELLECTOR_K_LOCUS_STATS);
