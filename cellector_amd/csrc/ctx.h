@@ -43,7 +43,8 @@ struct cellector_ctx {
     // side stream for the small overflow kernels that run next to the tile kernel (fork/join with events)
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    int overlap = 1;  // option "overlap": 1 = overflow kernels on the (low-priority) side stream next to the tile kernel
+    int overlap = 2;  // option "overlap": overflow kernels on the side stream next to the tile kernel: 2 = the whole chain,
+                      // 1 = only the per-cell gather (tables and values in front), 0 = nothing
     mutable std::string err;
 
     // options
@@ -107,6 +108,7 @@ struct cellector_ctx {
     double2 *ovf_val = nullptr;      // [3][ovf_n] (log-pmf, expected term) of overflow entries, by-locus order
     double *ovf_lp = nullptr;        // [ovf_n] the EM pass' overflow log-pmfs alone, by-locus order (locus pass)
     double *ovf_sum = nullptr;       // [3][2][nloc] per-cell sums of the overflow values (ll, expected) per table set
+    uint32_t *ovc_locus = nullptr;   // [ovf_n] compact locus index of every overflow entry, by-locus order
     uint32_t *ovf_nmask = nullptr;   // [L] which alt+ref totals (4..17) occur among the locus' overflow entries
     uint64_t *c4_ptr = nullptr;      // [L+1] compact CSC of regular entries
     uint32_t *c4_ent = nullptr;      // 32-bit entries cell_local | code << 28, or 24-bit cell | code << 20 (c4_bits)
@@ -120,6 +122,7 @@ struct cellector_ctx {
     uint32_t *masked_cnt = nullptr;  // [nloc] entries of the cell at masked loci
     uint32_t *flag_bits = nullptr;   // [ceil(nloc/32)] new exclusion set as a bitmask
     uint64_t n_masked_loci = 0;
+    uint32_t *tile_work = nullptr;   // [3][T_GROUPS_MAX] column counters of the persistent tile kernel, one set per table set
     uint32_t *minlist = nullptr;     // [nloc] local ids of the cells of the new exclusion set (arbitrary order)
     uint32_t *hist_min = nullptr;    // [lr_sub][L][16] regular entries of minority cells per (locus, code), partial planes
     uint32_t *mroff = nullptr;       // [R+1][mroff_cap] the excluded cells' offset rows, transposed (per iteration)

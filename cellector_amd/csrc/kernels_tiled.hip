@@ -35,6 +35,7 @@
 #define T_BC 1024       // cells per block == threads per workgroup
 #define T_THREADS 1024
 #define T_SB_MAX 4      // cell blocks per workgroup sharing one staged table (2 or 4: chosen per launch)
+#define T_GROUPS_MAX 64 // upper bound of the chunk groups of a launch
 #define T_GROUPS 8      // chunk groups (== XCDs: the workgroups of a group run on one XCD and share its L2)
 #define T_NE 15         // entries per cell of a slice held in registers (two 16-byte loads); longer slices: slow path
 #define T_NULL ((uint16_t)(T_NCODE * T_BL))  // padding entry: first element of the zero row
@@ -100,29 +101,41 @@ struct __attribute__((packed, aligned(4))) tile_u4 { uint32_t x, y, z, w; };  //
 
 template <bool EXPECTED, int T_SB>
 __global__ __launch_bounds__(T_THREADS, 4) void k_tile_ll(uint32_t nb, uint32_t nj, uint32_t cpg, uint32_t groups,
+                                                          uint32_t n_cols, uint32_t *__restrict__ work /*[groups], zeroed*/,
                                                           const uint16_t *__restrict__ thdr,
                                                           const uint16_t *__restrict__ tiles,
                                                           const double *__restrict__ tab, uint64_t npad,
                                                           double *__restrict__ part_ll, double *__restrict__ part_ell)
 {
-    // A workgroup owns T_SB consecutive 1024-cell blocks and one group of locus chunks.  Per chunk the table is staged
-    // ONCE in LDS and the T_SB tiles are walked one after the other; wave w takes slice w of each tile.  Everything a
-    // step needs was requested two steps earlier: in every step the values loaded before are consumed FIRST, then the
-    // next loads are issued as straight-line, unconditional instructions (indices are clamped instead of guarded).
+    // PERSISTENT workgroups, one per CU (the LDS footprint allows no second one): a workgroup belongs to one group of locus
+    // chunks (= one XCD, see below) and keeps fetching columns of T_SB consecutive 1024-cell blocks from the group's
+    // counter until none is left.  A grid of short-lived workgroups instead leaves a CU idle whenever the next one cannot
+    // start because waves of the small overflow kernels running beside this one still hold registers there (measured:
+    // 2.2 ms alone, 2.7 ms next to them).
+    // Per chunk the table is staged ONCE in LDS and the T_SB tiles are walked one after the other; wave w takes slice w of
+    // each tile.  Everything a step needs was requested two steps earlier: in every step the values loaded before are
+    // consumed FIRST, then the next loads are issued as straight-line, unconditional instructions (indices are clamped
+    // instead of guarded).
     using tab_t = typename std::conditional<EXPECTED, double2, double>::type;
     constexpr uint32_t TAB_U = T_ROWS * T_BL * sizeof(tab_t) / 16;  // 16-byte units per chunk table
     constexpr int NP = (TAB_U + T_THREADS - 1) / T_THREADS;         // units per thread (the last one partial)
     static_assert(NP == 6 || NP == 3, "table prefetch registers are written out by hand");
     __shared__ tab_t s_tab[T_ROWS * T_BL];
     __shared__ tab_t s_acc[T_SB * T_BC];  // per-cell sums of the workgroup's blocks
+    __shared__ uint32_t s_col;
     const uint32_t tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
-    // group = linear block id mod groups: with 8 groups all workgroups of a group land on the same XCD (round-robin
-    // dispatch), whose L2 then serves the group's table reads
-    const uint32_t g = blockIdx.x % groups, col = blockIdx.x / groups;
-    const uint32_t b0 = col * T_SB;
+    // group = linear block id mod groups: with a multiple of 8 groups all workgroups of a group land on the same XCD
+    // (round-robin dispatch), whose L2 then serves the group's table reads
+    const uint32_t g = blockIdx.x % groups;
     const uint32_t j0 = g * cpg, j1 = min(nj, j0 + cpg);
     if (j0 >= j1) return;
     const uint32_t n_steps = (j1 - j0) * T_SB;
+  for (;;) {
+    if (tid == 0) s_col = atomicAdd(&work[g], 1u);
+    __syncthreads();  // (also: the previous column's partial sums have been read out of s_acc)
+    const uint32_t col = s_col;
+    if (col >= n_cols) break;
+    const uint32_t b0 = col * T_SB;
 #pragma unroll
     for (int s = 0; s < T_SB; s++) {
         if constexpr (EXPECTED) s_acc[s * T_BC + tid] = make_double2(0.0, 0.0);
@@ -267,12 +280,6 @@ __global__ __launch_bounds__(T_THREADS, 4) void k_tile_ll(uint32_t nb, uint32_t 
             TILE_STEP(3, e1, h1);
         }
     }
-#undef TILE_STEP
-#undef TILE_LK
-#undef TILE_LOOKUP
-#undef ROW_LOAD
-#undef HDR_LOAD
-#undef TABLE_PREFETCH
     TILE_BARRIER();
 #pragma unroll
     for (int s = 0; s < T_SB; s++) {
@@ -283,6 +290,14 @@ __global__ __launch_bounds__(T_THREADS, 4) void k_tile_ll(uint32_t nb, uint32_t 
             else part_ll[c] = a;
         }
     }
+    __builtin_amdgcn_s_waitcnt(0);  // the pipeline's last (clamped, unused) loads have landed before the registers are reused
+  }
+#undef TILE_STEP
+#undef TILE_LK
+#undef TILE_LOOKUP
+#undef ROW_LOAD
+#undef HDR_LOAD
+#undef TABLE_PREFETCH
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -306,105 +321,111 @@ __device__ __noinline__ double ov_slow_expected(const double *lf, double alpha, 
 
 // ln sum_k pmf(k)^2 (stats.rs:8-22) for 4 <= n <= OV_NE by the pmf ratio recurrence of dm_expected_log_pmf, with pmf(0) built
 // from per-factor ratios (each in (0, 1]: no overflow of long products at these n)
+// 1 / y to about an ulp: v_rcp_f64 (good to ~27 bits) and one Newton step; no scaling / fix-up for subnormals or
+// infinities, which the arguments here (sums and products of counts) never are
+__device__ __forceinline__ double ov_rcp(double y)
+{
+    const double r = __builtin_amdgcn_rcp(y);
+    return __builtin_fma(__builtin_fma(-y, r, 1.0), r, r);
+}
 __device__ __forceinline__ double ov_expected_rec(double alpha, double beta, uint32_t n)
 {
+    // x / y as x * ov_rcp(y) instead of the ~25-instruction IEEE division: the few lanes that carry an E(n) keep their
+    // whole wave waiting, and 2 n ulp-sized errors are far inside the pass' tolerance
     const double ab = alpha + beta;
     double p = 1.0;
-    for (uint32_t j = 0; j < n; ++j) p *= (beta + (double)j) / (ab + (double)j);
+    for (uint32_t j = 0; j < n; ++j) p *= (beta + (double)j) * ov_rcp(ab + (double)j);
     double s = p * p;
     for (uint32_t k = 0; k < n; ++k) {
-        p *= ((double)(n - k) * (alpha + (double)k)) / ((double)(k + 1) * (beta + (double)(n - k - 1)));
+        p *= ((double)(n - k) * (alpha + (double)k)) * ov_rcp((double)(k + 1) * (beta + (double)(n - k - 1)));
         s += p * p;
     }
     return log(s);
 }
 
 // Per-locus overflow table (OV_ROW doubles): [0..17] LA[i] = sum_{m<i} ln(alpha+m), [18..35] LB, [36..53] LAB,
-// [64..] E(n) for n = 4..OV_NE.  32 lanes per locus: lane i < 17 takes the three logs of index i, a width-32 shuffle
-// scan turns them into the cumulative sums; lane i < 14 also takes E(4 + i) when an overflow entry of the locus has that
-// total (nmask: static), so that one launch serves the whole table.
+// [64..] E(n) for n = 4..OV_NE.  Two dense kernels (a fused one left most lanes of a wave idle while a few ran the long
+// loops): k_ovf_tables = one thread per (locus, family A / B / AB) running the 17 logs and their prefix sums;
+// k_ovf_tables_e = one thread per (locus, n) for the totals n that occur among the locus' overflow entries (nmask: static).
 #define OV_ROW 128
 #define OV_EOFF 64
-template <bool EXPECTED>
-__global__ __launch_bounds__(256) void k_ovf_tables(uint64_t L, const double2 *__restrict__ ab,
-                                                    const uint32_t *__restrict__ nmask, double *__restrict__ otab)
+__global__ __launch_bounds__(256) void k_ovf_tables(uint64_t L, const double2 *__restrict__ ab, double *__restrict__ otab)
 {
-    const uint64_t l = ((uint64_t)blockIdx.x * 256 + threadIdx.x) >> 5;
-    const int i = threadIdx.x & 31;
-    const bool in = l < L;
-    const double2 p = in ? ab[l] : make_double2(1.0, 1.0);
-    const bool live = p.x >= 0.0;
-    double ta = 0.0, tb = 0.0, tc = 0.0;
-    if (live && i < OV_NT - 1) {
-        ta = log(p.x + (double)i);
-        tb = log(p.y + (double)i);
-        tc = log((p.x + p.y) + (double)i);
-    }
-    double ia = ta, ib = tb, ic = tc;
-#pragma unroll
-    for (int off = 1; off < 32; off <<= 1) {
-        const double oa = __shfl_up(ia, off, 32), ob = __shfl_up(ib, off, 32), oc = __shfl_up(ic, off, 32);
-        if (i >= off) { ia += oa; ib += ob; ic += oc; }
-    }
-    if (!in) return;
-    double *row = otab + l * OV_ROW;
-    if (!live) {
-        if (i == 0) row[0] = -1.0;  // marks a masked locus
+    const uint64_t idx = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const uint64_t l = idx / 3;
+    if (l >= L) return;
+    const int fam = (int)(idx % 3);
+    const double2 p = ab[l];
+    double *row = otab + l * OV_ROW + fam * OV_NT;
+    if (!(p.x >= 0.0)) {
+        if (fam == 0) row[0] = -1.0;  // marks a masked locus
         return;
     }
-    if (i < OV_NT) {  // exclusive prefix: lane i holds the sum of the terms below i
-        row[i] = ia - ta;
-        row[OV_NT + i] = ib - tb;
-        row[2 * OV_NT + i] = ic - tc;
+    const double x0 = fam == 0 ? p.x : (fam == 1 ? p.y : p.x + p.y);
+    double acc = 0.0;
+    row[0] = 0.0;
+#pragma unroll
+    for (int i = 0; i < OV_NT - 1; i++) {
+        acc += log(x0 + (double)i);
+        row[i + 1] = acc;
     }
-    if (EXPECTED && i <= OV_NE - 4 && ((nmask[l] >> i) & 1u)) row[OV_EOFF + i] = ov_expected_rec(p.x, p.y, 4u + (uint32_t)i);
+}
+__global__ __launch_bounds__(256) void k_ovf_tables_e(uint64_t L, const double2 *__restrict__ ab,
+                                                      const uint32_t *__restrict__ nmask, double *__restrict__ otab)
+{
+    const uint64_t idx = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const uint64_t l = idx >> 4;  // 16 slots per locus, 14 used
+    if (l >= L) return;
+    const uint32_t i = (uint32_t)(idx & 15u);
+    if (i > (uint32_t)OV_NE - 4u || !((nmask[l] >> i) & 1u)) return;
+    const double2 p = ab[l];
+    if (!(p.x >= 0.0)) return;
+    otab[l * OV_ROW + OV_EOFF + i] = ov_expected_rec(p.x, p.y, 4u + i);
 }
 
+// one thread per overflow entry, by-locus order: neighbouring threads share a locus, so the four table words an entry
+// needs (LA[alt], LB[ref], LAB[n], E(n) of its locus' row) come out of L1; no per-locus loop, no cross-lane traffic
 template <bool EXPECTED>
-__global__ __launch_bounds__(256) void k_ovf_values(uint64_t L, const uint64_t *__restrict__ ovc_ptr,
+__global__ __launch_bounds__(256) void k_ovf_values(uint64_t n_ovf, const uint32_t *__restrict__ ovc_locus,
                                                     const uint64_t *__restrict__ ovc_ent,
                                                     const double2 *__restrict__ ab, const double *__restrict__ lf_g,
                                                     const double *__restrict__ otab, double2 *__restrict__ val,
                                                     double *__restrict__ lp_only /*may be null: the locus pass' copy*/)
 {
-    __shared__ double lf[LF_TABLE_N];
-    for (int i = threadIdx.x; i < LF_TABLE_N; i += 256) lf[i] = lf_g[i];
-    __syncthreads();
-    const int lane = threadIdx.x & 63;
-    const uint64_t wave0 = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (uint64_t)gridDim.x * 4;
-    for (uint64_t l = wave0; l < L; l += nwaves) {
-        const uint64_t beg = ovc_ptr[l], end = ovc_ptr[l + 1];
-        if (beg == end) continue;
-        const double2 p = ab[l];
-        if (!(p.x >= 0.0)) {  // masked locus: no PMFData (main.rs:556)
-            for (uint64_t i = beg + lane; i < end; i += 64) {
-                val[i] = make_double2(0.0, 0.0);
-                if (lp_only) lp_only[i] = 0.0;
-            }
-            continue;
+    const double *lf = lf_g;  // 1.4 KB: L1-resident (a per-block copy in LDS costs a load + barrier before any work)
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_ovf) return;
+    const uint32_t l = ovc_locus[i];
+    const uint64_t en = ovc_ent[i];
+    const double *row = otab + (uint64_t)l * OV_ROW;
+    double lp = 0.0, ee = 0.0;
+    if (row[0] >= 0.0) {  // else a masked locus: no PMFData (main.rs:556)
+        const uint32_t a = ENT_ALT(en), r = ENT_REF(en), n = a + r;
+        if (n == 0) lp = 0.0;  // quirk Q14: exactly zero
+        else if (n < (uint32_t)OV_NT) lp = dm_ln_choose(lf, a, r) + (row[a] + row[OV_NT + r] - row[2 * OV_NT + n]);
+        else {
+            const double2 p = ab[l];
+            lp = ov_slow_log_pmf(lf, p.x, p.y, a, r);
         }
-        const double tv = otab[l * OV_ROW + lane];              // cumulative log tables, one value per lane
-        const double tw = otab[l * OV_ROW + OV_EOFF + lane];    // expected terms
-        for (uint64_t i0 = beg; i0 < end; i0 += 64) {
-            const uint64_t i = i0 + lane;
-            const bool in = i < end;
-            const uint64_t en = in ? ovc_ent[i] : 0;
-            const uint32_t a = ENT_ALT(en), r = ENT_REF(en), n = a + r;
-            const bool fast = n < (uint32_t)OV_NT;
-            const double la = __shfl(tv, (int)min(a, (uint32_t)OV_NT - 1), 64);
-            const double lb = __shfl(tv, OV_NT + (int)min(r, (uint32_t)OV_NT - 1), 64);
-            const double lab = __shfl(tv, 2 * OV_NT + (int)min(n, (uint32_t)OV_NT - 1), 64);
-            const double ex = __shfl(tw, (int)(min(max(n, 4u), (uint32_t)OV_NE) - 4u), 64);
-            if (!in) continue;
-            double lp, ee = 0.0;
-            if (n == 0) lp = 0.0;  // quirk Q14: exactly zero
-            else if (fast) lp = dm_ln_choose(lf, a, r) + (la + lb - lab);
-            else lp = ov_slow_log_pmf(lf, p.x, p.y, a, r);
-            if (EXPECTED && n != 0) ee = (n >= 4 && n <= (uint32_t)OV_NE) ? ex : ov_slow_expected(lf, p.x, p.y, n);
-            val[i] = make_double2(lp, ee);
-            if (lp_only) lp_only[i] = lp;  // the locus pass streams this: half the bytes of the pairs
+        if (EXPECTED && n != 0) {
+            if (n >= 4 && n <= (uint32_t)OV_NE) ee = row[OV_EOFF + (n - 4)];
+            else {
+                const double2 p = ab[l];
+                ee = ov_slow_expected(lf, p.x, p.y, n);
+            }
         }
     }
+    val[i] = make_double2(lp, ee);
+    if (lp_only) lp_only[i] = lp;  // the locus pass streams this: half the bytes of the pairs
+}
+
+// locus of every overflow entry (by-locus order): wave per locus
+__global__ __launch_bounds__(256) void k_ovf_locus_ids(uint64_t L, const uint64_t *__restrict__ ovc_ptr, uint32_t *__restrict__ ovc_locus)
+{
+    const int lane = threadIdx.x & 63;
+    const uint64_t wave0 = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (uint64_t)gridDim.x * 4;
+    for (uint64_t l = wave0; l < L; l += nwaves)
+        for (uint64_t i = ovc_ptr[l] + lane; i < ovc_ptr[l + 1]; i += 64) ovc_locus[i] = (uint32_t)l;
 }
 
 // perm[position in the by-cell overflow array] = position in the by-locus overflow array
@@ -1182,7 +1203,7 @@ void tiled_free(cellector_ctx *c)
     dev_free(c->c4_ptr); dev_free(c->c4_ent); dev_free(c->ovc_ptr); dev_free(c->ovc_ent);
     dev_free(c->hist_all); dev_free(c->tab); dev_free(c->part); dev_free(c->ab3);
     dev_free(c->masked_cnt); dev_free(c->flag_bits); dev_free(c->ovf_perm); dev_free(c->ovf_val); dev_free(c->ovf_tab);
-    dev_free(c->ovf_sum); dev_free(c->ovf_lp); dev_free(c->ovf_nmask); dev_free(c->minlist); dev_free(c->hist_min); dev_free(c->roff); dev_free(c->mroff); dev_free(c->mbeg);
+    dev_free(c->ovf_sum); dev_free(c->ovf_lp); dev_free(c->ovc_locus); dev_free(c->ovf_nmask); dev_free(c->tile_work); dev_free(c->minlist); dev_free(c->hist_min); dev_free(c->roff); dev_free(c->mroff); dev_free(c->mbeg);
     c->mroff_cap = 0;
     c->tiled_ready = false;
     c->ovf_n = 0; c->n_masked_loci = 0;
@@ -1196,15 +1217,16 @@ cellector_status tiled_build(cellector_ctx *c)
     c->t_nj = (uint32_t)((L + T_BL - 1) / T_BL);
     if (c->t_nb == 0) c->t_nb = 1;
     if (c->t_nj == 0) c->t_nj = 1;
-    // Chunk groups: a multiple of the 8 XCDs (workgroup i runs on XCD i mod 8, so a group's workgroups share one L2),
-    // more of them when the shard has few cell blocks, so that the tile kernel still launches several rounds of
-    // workgroups per CU (one workgroup per CU at a time) — at the price of one more partial sum per cell and group.
+    // Chunk groups: a multiple of the 8 XCDs (workgroup i runs on XCD i mod 8, so a group's workgroups share one L2).  The
+    // tile kernel runs one persistent workgroup per CU, each bound to a group and fetching columns of T_SB_MAX cell
+    // blocks: 8 groups when there are at least CUs / 8 columns, more groups for a smaller shard so that every CU still
+    // gets a (group, column) pair — at the price of one more partial sum per cell and group.
     {
         int ncu = 256;
         (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, c->device);
-        const uint64_t cols = (c->t_nb + T_SB_MAX - 1) / T_SB_MAX, want = 4ull * (uint64_t)ncu;
-        uint64_t groups = T_GROUPS * ((want + cols * T_GROUPS - 1) / (cols * T_GROUPS));
-        if (groups > 64) groups = 64;
+        const uint64_t cols = (c->t_nb + T_SB_MAX - 1) / T_SB_MAX;
+        uint64_t groups = T_GROUPS * (((uint64_t)ncu + cols * T_GROUPS - 1) / (cols * T_GROUPS));
+        if (groups > T_GROUPS_MAX) groups = T_GROUPS_MAX;
         if (groups > c->t_nj) groups = c->t_nj;
         c->t_groups = (uint32_t)groups;
     }
@@ -1291,6 +1313,9 @@ cellector_status tiled_build(cellector_ctx *c)
     CHK(dev_alloc(c, &c->ovf_lp, c->ovf_n));
     CHK(dev_alloc(c, &c->ovf_tab, L * OV_ROW));
     CHK(dev_alloc(c, &c->ovf_nmask, L));
+    CHK(dev_alloc(c, &c->ovc_locus, c->ovf_n));
+    if (L && c->ovf_n)
+        hipLaunchKernelGGL(k_ovf_locus_ids, dim3(gcap(L, 4)), dim3(256), 0, c->stream, L, c->ovc_ptr, c->ovc_locus);
     if (L && c->ovf_n) {
         hipLaunchKernelGGL(k_ovf_perm, dim3(gcap(L, 4)), dim3(256), 0, c->stream, L, c->ovc_ptr, c->ovc_ent, c->ovf_ptr,
                            c->ovf_ent, c->ovf_perm);
@@ -1309,6 +1334,7 @@ cellector_status tiled_build(cellector_ctx *c)
     CHK(dev_alloc(c, &c->ab3, 3 * L));
     CHK(dev_alloc(c, &c->masked_cnt, nloc));
     CHK(dev_alloc(c, &c->flag_bits, (nloc + 31) / 32 + 1));
+    CHK(dev_alloc(c, &c->tile_work, 3 * T_GROUPS_MAX));
     CHK(dev_alloc(c, &c->minlist, nloc));
     {
         // subsets of the exclusion set: enough (range, subset) workgroups to fill the chip once
@@ -1335,22 +1361,33 @@ cellector_status tiled_build(cellector_ctx *c)
 
 // Overflow side of one pass: tables -> per-entry values (locus-major) -> per-cell sums.  Launched on the side stream so
 // that these small, latency-bound kernels run next to the tile kernel instead of in front of it.
-static void launch_overflow_pass(cellector_ctx *c, hipStream_t st, const double2 *ab, int set, bool expected)
+// Overflow side of one pass: per-locus tables -> per-entry values (by-locus order) on stream `st`, then the per-cell
+// gather of those values on stream `sg` (which may run beside the tile kernel: it is memory latency, hardly any ALU).
+static void launch_overflow_values(cellector_ctx *c, hipStream_t st, const double2 *ab, int set, bool expected)
 {
     double2 *val = c->ovf_val + (uint64_t)set * c->ovf_n;
-    double *o_ll = c->ovf_sum + (uint64_t)set * 2 * c->nloc, *o_ell = o_ll + c->nloc;
-    const unsigned tg = gcap(c->L * 32, 256, 0x7fffffffu), vg = gcap(c->L, 4, 4096), sg = gcap(c->nloc, 256, 0x7fffffffu);
+    double *lp_only = set == 0 ? c->ovf_lp : (double *)nullptr;
+    const unsigned tg = gcap(c->L * 3, 256, 0x7fffffffu), eg = gcap(c->L * 16, 256, 0x7fffffffu),
+                   vg = gcap(c->ovf_n, 256, 0x7fffffffu);
+    hipLaunchKernelGGL(k_ovf_tables, dim3(tg), dim3(256), 0, st, c->L, ab, c->ovf_tab);
     if (expected) {
-        hipLaunchKernelGGL(k_ovf_tables<true>, dim3(tg), dim3(256), 0, st, c->L, ab, c->ovf_nmask, c->ovf_tab);
-        hipLaunchKernelGGL(k_ovf_values<true>, dim3(vg), dim3(256), 0, st, c->L, c->ovc_ptr, c->ovc_ent, ab, c->lf, c->ovf_tab, val,
-                           set == 0 ? c->ovf_lp : (double *)nullptr);
-        hipLaunchKernelGGL(k_ovf_cell_sums<true>, dim3(sg), dim3(256), 0, st, c->nloc, c->ovf_ptr, c->ovf_perm, val, o_ll, o_ell);
+        hipLaunchKernelGGL(k_ovf_tables_e, dim3(eg), dim3(256), 0, st, c->L, ab, c->ovf_nmask, c->ovf_tab);
+        hipLaunchKernelGGL(k_ovf_values<true>, dim3(vg), dim3(256), 0, st, c->ovf_n, c->ovc_locus, c->ovc_ent, ab, c->lf, c->ovf_tab,
+                           val, lp_only);
     } else {
-        hipLaunchKernelGGL(k_ovf_tables<false>, dim3(tg), dim3(256), 0, st, c->L, ab, c->ovf_nmask, c->ovf_tab);
-        hipLaunchKernelGGL(k_ovf_values<false>, dim3(vg), dim3(256), 0, st, c->L, c->ovc_ptr, c->ovc_ent, ab, c->lf, c->ovf_tab, val,
-                           set == 0 ? c->ovf_lp : (double *)nullptr);
-        hipLaunchKernelGGL(k_ovf_cell_sums<false>, dim3(sg), dim3(256), 0, st, c->nloc, c->ovf_ptr, c->ovf_perm, val, o_ll, o_ell);
+        hipLaunchKernelGGL(k_ovf_values<false>, dim3(vg), dim3(256), 0, st, c->ovf_n, c->ovc_locus, c->ovc_ent, ab, c->lf, c->ovf_tab,
+                           val, lp_only);
     }
+}
+static void launch_overflow_gather(cellector_ctx *c, hipStream_t sg, int set, bool expected)
+{
+    const double2 *val = c->ovf_val + (uint64_t)set * c->ovf_n;
+    double *o_ll = c->ovf_sum + (uint64_t)set * 2 * c->nloc, *o_ell = o_ll + c->nloc;
+    const unsigned g = gcap(c->nloc, 256, 0x7fffffffu);
+    if (expected)
+        hipLaunchKernelGGL(k_ovf_cell_sums<true>, dim3(g), dim3(256), 0, sg, c->nloc, c->ovf_ptr, c->ovf_perm, val, o_ll, o_ell);
+    else
+        hipLaunchKernelGGL(k_ovf_cell_sums<false>, dim3(g), dim3(256), 0, sg, c->nloc, c->ovf_ptr, c->ovf_perm, val, o_ll, o_ell);
 }
 
 static bool have_overflow(const cellector_ctx *c) { return c->ovf_n != 0 && c->L != 0 && c->nloc != 0; }
@@ -1370,13 +1407,11 @@ static cellector_status side_join(cellector_ctx *c)
     return CELLECTOR_OK;
 }
 
-// table build + tile kernel of one pass on the main stream
-static cellector_status run_tile_pass(cellector_ctx *c, const double2 *ab, int set, bool expected)
+// the chunk tables of one pass
+static cellector_status build_tile_tables(cellector_ctx *c, const double2 *ab, int set, bool expected)
 {
     const uint64_t tab_elems = (uint64_t)c->t_nj * TAB_ELEMS;
     double *tab = expected ? c->tab + 3 * tab_elems : c->tab + (uint64_t)set * tab_elems;
-    double *part_ll = c->part + (uint64_t)set * 2 * c->t_groups * c->t_npad;
-    double *part_ell = part_ll + (uint64_t)c->t_groups * c->t_npad;
     const unsigned tgrid = gcap((uint64_t)c->t_nj * T_BL, 256);
     if (expected)
         hipLaunchKernelGGL(k_build_tables<true>, dim3(tgrid), dim3(256), 0, c->stream, c->L, c->t_nj, ab, c->lf, tab);
@@ -1386,14 +1421,34 @@ static cellector_status run_tile_pass(cellector_ctx *c, const double2 *ab, int s
         c->tab_em = tab;
         c->tab_em_stride = expected ? 2 : 1;
     }
-    // several cell blocks per workgroup amortise the table staging; with few blocks (small shard) prefer more workgroups
+    HIPCHK(c, hipGetLastError());
+    return CELLECTOR_OK;
+}
+
+// tile kernel of one pass on the main stream (its tables are built)
+static cellector_status run_tile_pass(cellector_ctx *c, int set, bool expected)
+{
+    const uint64_t tab_elems = (uint64_t)c->t_nj * TAB_ELEMS;
+    double *tab = expected ? c->tab + 3 * tab_elems : c->tab + (uint64_t)set * tab_elems;
+    double *part_ll = c->part + (uint64_t)set * 2 * c->t_groups * c->t_npad;
+    double *part_ell = part_ll + (uint64_t)c->t_groups * c->t_npad;
+    // several cell blocks per column amortise the table staging; with few blocks (small shard) prefer more columns
+    int ncu = 256;
+    (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, c->device);
     int sb = T_SB_MAX;
-    while (sb > 2 && (uint64_t)((c->t_nb + sb - 1) / sb) * c->t_groups < 512) sb >>= 1;
-    const dim3 grid(((c->t_nb + sb - 1) / sb) * c->t_groups);
+    while (sb > 2 && (uint64_t)((c->t_nb + sb - 1) / sb) * c->t_groups < (uint64_t)ncu) sb >>= 1;
+    const uint32_t n_cols = (c->t_nb + sb - 1) / sb;
+    // persistent workgroups: one per CU, an equal number for every chunk group, never more than there are columns
+    uint32_t per_group = (uint32_t)ncu / c->t_groups;
+    if (per_group < 1) per_group = 1;
+    if (per_group > n_cols) per_group = n_cols;
+    const dim3 grid(per_group * c->t_groups);
+    uint32_t *work = c->tile_work + (size_t)set * T_GROUPS_MAX;
+    HIPCHK(c, hipMemsetAsync(work, 0, T_GROUPS_MAX * sizeof(uint32_t), c->stream));
     timer_begin(c, CELLECTOR_K_TILE_LL);
 #define LAUNCH_TILE(E, S)                                                                                                  \
-    hipLaunchKernelGGL((k_tile_ll<E, S>), grid, dim3(T_THREADS), 0, c->stream, c->t_nb, c->t_nj, c->t_cpg, c->t_groups, c->thdr, \
-                       c->tiles, tab, c->t_npad, part_ll, part_ell)
+    hipLaunchKernelGGL((k_tile_ll<E, S>), grid, dim3(T_THREADS), 0, c->stream, c->t_nb, c->t_nj, c->t_cpg, c->t_groups, n_cols, \
+                       work, c->thdr, c->tiles, tab, c->t_npad, part_ll, part_ell)
     if (expected) {
         if (sb == 4) LAUNCH_TILE(true, 4); else LAUNCH_TILE(true, 2);
     } else {
@@ -1410,16 +1465,21 @@ cellector_status tiled_cell_pass(cellector_ctx *c, const double2 *ab, double *no
     if (c->nloc == 0) return CELLECTOR_OK;
     timer_begin(c, CELLECTOR_K_CELL_LL);
     const bool ovf = have_overflow(c);
+    // The overflow chain (tables -> values -> per-cell gather) runs on the side stream beside the tile kernel (overlap 2):
+    // the tile kernel's persistent workgroups leave few wave slots, so the chain is several times slower there than
+    // alone (1.6 against 0.7 ms at cfg4), but it ends well inside the tile kernel's 2.5 ms and costs that kernel 0.27 ms,
+    // less than running any part of it in front (overlap 1: only the gather beside it; 0: nothing).
+    if (ovf && c->overlap != 2) launch_overflow_values(c, c->stream, ab, 0, c->compute_expected);
+    CHK(build_tile_tables(c, ab, 0, c->compute_expected));
     if (ovf && c->overlap) {
-        // the side stream may start now, but its kernels are submitted AFTER the tile kernel: they fill the wave slots
-        // the tile workgroups (one per CU, 16 of its 32 wave slots) leave free instead of taking CUs away from them
         CHK(side_fork(c));
-        CHK(run_tile_pass(c, ab, 0, c->compute_expected));
-        launch_overflow_pass(c, c->side, ab, 0, c->compute_expected);
+        if (c->overlap == 2) launch_overflow_values(c, c->side, ab, 0, c->compute_expected);
+        launch_overflow_gather(c, c->side, 0, c->compute_expected);
+        CHK(run_tile_pass(c, 0, c->compute_expected));
         CHK(side_join(c));
     } else {
-        if (ovf) launch_overflow_pass(c, c->stream, ab, 0, c->compute_expected);
-        CHK(run_tile_pass(c, ab, 0, c->compute_expected));
+        if (ovf) launch_overflow_gather(c, c->stream, 0, c->compute_expected);
+        CHK(run_tile_pass(c, 0, c->compute_expected));
     }
     double *part_ll = c->part, *part_ell = c->part + (uint64_t)c->t_groups * c->t_npad;
     const double *o_ll = ovf ? c->ovf_sum : nullptr, *o_ell = ovf ? c->ovf_sum + c->nloc : nullptr;
@@ -1524,15 +1584,21 @@ cellector_status tiled_posteriors(cellector_ctx *c, double mf0, double lp_min, d
     if (c->nloc == 0) return CELLECTOR_OK;
     timer_begin(c, CELLECTOR_K_POSTERIOR);
     const bool ovf = have_overflow(c);
+    if (ovf && c->overlap != 2)
+        for (int set = 0; set < 3; set++) launch_overflow_values(c, c->stream, c->ab3 + (uint64_t)set * L, set, false);
+    for (int set = 0; set < 3; set++) CHK(build_tile_tables(c, c->ab3 + (uint64_t)set * L, set, false));
     if (ovf && c->overlap) {
         CHK(side_fork(c));
-        for (int set = 0; set < 3; set++) CHK(run_tile_pass(c, c->ab3 + (uint64_t)set * L, set, false));
-        for (int set = 0; set < 3; set++) launch_overflow_pass(c, c->side, c->ab3 + (uint64_t)set * L, set, false);
+        for (int set = 0; set < 3; set++) {
+            if (c->overlap == 2) launch_overflow_values(c, c->side, c->ab3 + (uint64_t)set * L, set, false);
+            launch_overflow_gather(c, c->side, set, false);
+        }
+        for (int set = 0; set < 3; set++) CHK(run_tile_pass(c, set, false));
         CHK(side_join(c));
     } else {
         if (ovf)
-            for (int set = 0; set < 3; set++) launch_overflow_pass(c, c->stream, c->ab3 + (uint64_t)set * L, set, false);
-        for (int set = 0; set < 3; set++) CHK(run_tile_pass(c, c->ab3 + (uint64_t)set * L, set, false));
+            for (int set = 0; set < 3; set++) launch_overflow_gather(c, c->stream, set, false);
+        for (int set = 0; set < 3; set++) CHK(run_tile_pass(c, set, false));
     }
     hipLaunchKernelGGL(k_posterior_finalize, dim3(gcap(c->nloc, 256, 0x7fffffffu)), dim3(256), 0, c->stream, c->nloc,
                        ovf ? c->ovf_sum : (const double *)nullptr, c->t_groups, c->t_npad, c->part, lp_min, lp_maj, lp_dbl, c->post);
