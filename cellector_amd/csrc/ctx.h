@@ -95,16 +95,16 @@ struct cellector_ctx {
     bool tiled_ready = false;
     uint32_t t_nb = 0, t_nj = 0, t_groups = 0, t_cpg = 0;  // cell blocks, locus chunks, chunk groups, chunks/group
     uint64_t t_npad = 0;             // nb * T_BC
-    uint64_t *tile_ptr = nullptr;    // [nb*nj+1] offsets into tiles, in u16 elements (multiples of 8)
-    uint16_t *tiles = nullptr;       // entry stream: per tile its u16 entries code<<9 | locus_in_chunk, cells in order
-    uint16_t *thdr = nullptr;        // [nb*nj][T_HDR] tile headers (per-wave base + per-cell offsets)
+    uint64_t *tile_ptr = nullptr;    // [nb*nj+1] offsets into tiles, in u16 elements (multiples of 128)
+    uint16_t *tiles = nullptr;       // SELL-64-1024 slices: per tile 16 slices of 64 rows [cell, K entries code*384 + locus_in_chunk]
+    uint16_t *thdr = nullptr;        // [nb*nj][T_HDR] tile headers: 16 x {first u16 of the slice, K}
     uint64_t t_elems = 0;            // entries (u16) in the stream, padding included
     double *tab_em = nullptr;        // table the last EM cell pass built (the locus pass reads its log-pmfs)
     int tab_em_stride = 1;           // 2 when that table holds (log-pmf, expected) pairs
-    uint64_t *ovf_ptr = nullptr, *ovf_ent = nullptr;    // overflow CSR (n == 0 or n > 3), packed like csr_ent
+    uint64_t *ovf_ptr = nullptr, *ovf_ent = nullptr;    // overflow CSR (alt+ref == 0 or > 4), packed like csr_ent
     uint64_t ovf_n = 0;
     uint32_t *ovf_perm = nullptr;    // [ovf_n] by-cell position -> by-locus position
-    double *ovf_tab = nullptr;       // [L][64] per-locus cumulative-log / expected tables for overflow entries
+    double *ovf_tab = nullptr;       // [L][128] per-locus cumulative-log / expected tables for overflow entries
     double2 *ovf_val = nullptr;      // [3][ovf_n] (log-pmf, expected term) of overflow entries, by-locus order
     double *ovf_lp = nullptr;        // [ovf_n] the EM pass' overflow log-pmfs alone, by-locus order (locus pass)
     double *ovf_sum = nullptr;       // [3][2][nloc] per-cell sums of the overflow values (ll, expected) per table set
@@ -115,8 +115,8 @@ struct cellector_ctx {
     int c4_bits = 32;
     int c4_bits_opt = 0;             // option "compact_bits": 0 = automatic, 32 = force the 32-bit entries
     uint64_t *ovc_ptr = nullptr, *ovc_ent = nullptr;    // overflow CSC, packed like csc_ent
-    uint32_t *hist_all = nullptr;    // [L][9] regular entries per code
-    double *tab = nullptr;           // [3][nj][12][512] log-pmf / expected tables (set 0: EM pass; 0..2: posterior)
+    uint32_t *hist_all = nullptr;    // [L][14] regular entries per code
+    double *tab = nullptr;           // [3 + 2][nj][15][384] log-pmf tables of the posterior sets, then the EM pass' (log-pmf, expected) pairs
     double *part = nullptr;          // [3][2][groups][npad] per-group partial sums (ll, ell)
     double2 *ab3 = nullptr;          // [3][L] posterior alpha/beta sets as double2
     uint32_t *masked_cnt = nullptr;  // [nloc] entries of the cell at masked loci
