@@ -17,10 +17,12 @@
 //               accumulator in LDS (the lane <-> cell assignment changes from tile to tile).  The kernel is bound by
 //               the LDS pipe (random 16-byte lookups, ~12 clk per wave instruction: tools/probe/lds_probe.hip).
 //               No transcendental, no atomics; a cell's sum runs over its chunks in order and inside a chunk in
-//               ascending-locus order: bit-deterministic and independent of the sharding.
-//   locus pass  (get_locus_log_likelihoods, main.rs:368-420): compact CSC of 24/32-bit entries (cell | code); the new
-//               exclusion set is a bitmask staged in LDS; a wave per locus counts minority entries per code;
-//               contributions are count x table value; the majority side is (static histogram - minority).
+//               ascending-locus order: bit-deterministic (the number of chunk groups fixes how the partials associate).
+//   locus pass  (get_locus_log_likelihoods, main.rs:368-420): all outputs follow from the minority cells' entry counts per
+//               (locus, code): contributions are count x table value; the majority side is (static histogram - minority).
+//               The counts come either from walking only the excluded cells' CSR rows into LDS range histograms
+//               (k_minority_ranges: the usual case, a few percent of the matrix) or from streaming a compact CSC of
+//               24/32-bit entries (cell | code) past the exclusion bitmask in LDS (k_locus_stats2); chosen on the device.
 //   overflow    entries with n == 0 or n > 4 (~1 %) live in a small CSR/CSC in the v1 packed format; their values are
 //               computed once per pass in locus-major order and gathered.
 #include <type_traits>
