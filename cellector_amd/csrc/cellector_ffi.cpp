@@ -117,7 +117,8 @@ cellector_status cellector_create(cellector_ctx **out, int device_id)
               hipMalloc((void **)&c->sel_hist, SEL_T * 256 * sizeof(uint32_t)) == hipSuccess &&
               hipMalloc((void **)&c->sel_state, 4 * SEL_T * sizeof(uint64_t)) == hipSuccess &&
               hipMalloc((void **)&c->sel_out, 16 * sizeof(double)) == hipSuccess &&
-              hipHostMalloc((void **)&c->h_sel, 16 * sizeof(double)) == hipSuccess &&
+              hipHostMalloc((void **)&c->h_sel, 32 * sizeof(double)) == hipSuccess &&
+              hipHostGetDevicePointer((void **)&c->h_sum_dev, c->h_sel, 0) == hipSuccess &&
               create_side_stream(&c->side) &&
               hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) == hipSuccess &&
               hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) == hipSuccess;
@@ -439,8 +440,10 @@ cellector_status cellector_em_begin(cellector_ctx *c)
     CHK(launch_alpha_beta(c));
     if (c->nloc != c->total_cells)  // other shards' slices must be zero before the sum-exchange
         HIPCHK(c, hipMemsetAsync(c->x_norm, 0, c->total_cells * 8, c->stream));
-    if (c->engine == 2) CHK(tiled_cell_pass(c, c->ab, c->x_norm + c->cell_begin));
-    else CHK(launch_cell_ll(c, c->ab, c->x_norm + c->cell_begin));
+    cellector_status st = c->engine == 2 ? tiled_cell_pass(c, c->ab, c->x_norm + c->cell_begin)
+                                         : launch_cell_ll(c, c->ab, c->x_norm + c->cell_begin);
+    c->work_zeroed = false;  // (only this iteration's first tile pass may rely on k_alpha_beta's reset)
+    CHK(st);
     c->em_phase = 1;
     return CELLECTOR_OK;
 }
@@ -455,8 +458,7 @@ cellector_status cellector_em_threshold(cellector_ctx *c, double iqr_multiple)
     REQUIRE(c, n > 0, "no cells");
     // exact median / R-8 quartiles / threshold, all on the device (no host round trip in this phase)
     CHK(select_threshold(c, c->x_norm, n, iqr_multiple));
-    HIPCHK(c, hipMemsetAsync(c->x_locus + (uint64_t)LB_PLANES * c->L, 0, LC_COUNTERS * 8, c->stream));
-    HIPCHK(c, hipMemsetAsync(c->d_counters + DC_N_MIN, 0, sizeof(uint32_t), c->stream));
+    // (the counters k_flag adds to were reset by this iteration's k_alpha_beta)
     CHK(launch_flag(c, c->sel_out + 10));
     if (c->engine == 2) CHK(tiled_locus_pass(c));
     else CHK(launch_locus_stats(c));
@@ -470,15 +472,14 @@ cellector_status cellector_em_finish(cellector_ctx *c, cellector_iter_summary *o
     READY(c);
     REQUIRE(c, c->em_phase == 2, "em_finish without em_threshold");
     SETDEV(c);
-    HIPCHK(c, hipMemsetAsync(c->d_counters, 0, 8 * sizeof(uint32_t), c->stream));
     CHK(launch_locus_filter(c));
-    double cnt[LC_COUNTERS];
-    uint32_t dc[8];
-    HIPCHK(c, hipMemcpyAsync(cnt, c->x_locus + (uint64_t)LB_PLANES * c->L, sizeof cnt, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(dc, c->d_counters, sizeof dc, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->h_sel, c->sel_out + 8, 3 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    CHK(launch_iter_summary(c));
     HIPCHK(c, hipStreamSynchronize(c->stream));  // the iteration's only host synchronisation
-    c->last_median = c->h_sel[0]; c->last_iqr = c->h_sel[1]; c->last_thr = c->h_sel[2];
+    double cnt[LC_COUNTERS];
+    uint32_t dc[8] = {0};
+    for (int i = 0; i < LC_COUNTERS; i++) cnt[i] = c->h_sel[i];
+    dc[0] = (uint32_t)c->h_sel[LC_COUNTERS];
+    c->last_median = c->h_sel[LC_COUNTERS + 1]; c->last_iqr = c->h_sel[LC_COUNTERS + 2]; c->last_thr = c->h_sel[LC_COUNTERS + 3];
     if (dc[0]) {
         c->n_masked_loci += dc[0];
         if (c->tiled_ready) CHK(tiled_masked_update(c));

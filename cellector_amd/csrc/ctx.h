@@ -29,6 +29,8 @@ enum { P1_CELLS_REF = 0, P1_CELLS_ALT = 1, P1_SUM_REF = 2, P1_SUM_ALT = 3, P1_EN
 // d_counters slots (u32)
 enum { DC_N_FILTERED = 0, DC_N_MIN = 4 /* members of this shard's new exclusion set (k_flag) */ };
 
+#define CELLECTOR_TILE_WORK_STRIDE 64  // column counters per table set of the persistent tile kernel (= T_GROUPS_MAX)
+
 #define LF_TABLE_N 171  // ln(FCACHE[0..170]) — statrs ln_factorial cache, SURVEY Appendix B.2
 
 struct KernelTimer {
@@ -137,7 +139,9 @@ struct cellector_ctx {
     uint32_t *sel_hist = nullptr;   // [SEL_T][256]
     uint64_t *sel_state = nullptr;  // [SEL_T][2] prefix, remaining rank; then the ticket counter
     double *sel_out = nullptr;      // [16] device: [0..5] order statistics, [8..10] median, iqr, threshold
-    double *h_sel = nullptr;        // pinned [16]: iteration summary read back in em_finish
+    double *h_sel = nullptr;        // pinned [32]: iteration summary written by k_iter_summary, read in em_finish
+    double *h_sum_dev = nullptr;    // the device's address of h_sel
+    bool work_zeroed = false;       // tile_work was reset by this iteration's k_alpha_beta
 
     // iteration bookkeeping
     uint64_t iteration = 0;
@@ -195,6 +199,7 @@ cellector_status launch_cell_ll(cellector_ctx *c, const double2 *ab, double *nor
 cellector_status launch_flag(cellector_ctx *c, const double *d_thr);
 cellector_status launch_locus_stats(cellector_ctx *c);
 cellector_status launch_locus_filter(cellector_ctx *c);
+cellector_status launch_iter_summary(cellector_ctx *c);
 cellector_status launch_ab_from_host(cellector_ctx *c, const double *alpha, const double *beta,
                                      const uint8_t *mask);
 cellector_status launch_posteriors(cellector_ctx *c, double mf0, double lp_min, double lp_maj,

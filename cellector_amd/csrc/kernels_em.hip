@@ -16,8 +16,16 @@
 // ---------------------------------------------------------------------------------------------------
 __global__ void k_alpha_beta(uint64_t L, const double *__restrict__ s_alt, const double *__restrict__ s_ref,
                              const double *__restrict__ alt_min, const double *__restrict__ ref_min,
-                             const uint8_t *__restrict__ mask, double2 *__restrict__ ab)
+                             const uint8_t *__restrict__ mask, double2 *__restrict__ ab,
+                             double *__restrict__ xl_counters, uint32_t *__restrict__ d_counters,
+                             uint32_t *__restrict__ tile_work, uint32_t n_work)
 {
+    // first kernel of an iteration: it also resets the iteration's small counters (instead of one memset each)
+    if (blockIdx.x == 0 && xl_counters) {
+        if (threadIdx.x < LC_COUNTERS) xl_counters[threadIdx.x] = 0.0;
+        if (threadIdx.x < 8) d_counters[threadIdx.x] = 0u;
+        for (uint32_t i = threadIdx.x; i < n_work; i += blockDim.x) tile_work[i] = 0u;
+    }
     uint64_t l = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (l >= L) return;
     double2 v;
@@ -299,6 +307,16 @@ __global__ void k_final_tallies(uint64_t n, uint64_t total_loci, const uint32_t 
     if (ref[i]) atomicAdd(&out[base + total_loci + l], (unsigned long long)ref[i]);
 }
 
+// the iteration's summary, written straight into pinned host memory (one kernel instead of three small copies)
+__global__ void k_iter_summary(const double *__restrict__ xl_counters, const uint32_t *__restrict__ d_counters,
+                               const double *__restrict__ sel, double *__restrict__ h_sum)
+{
+    const int t = threadIdx.x;
+    if (t < LC_COUNTERS) h_sum[t] = xl_counters[t];
+    else if (t == LC_COUNTERS) h_sum[t] = (double)d_counters[DC_N_FILTERED];
+    else if (t < LC_COUNTERS + 4) h_sum[t] = sel[t - LC_COUNTERS - 1];  // median, iqr, threshold
+}
+
 // ===================================================================================================
 // launch wrappers
 // ===================================================================================================
@@ -313,8 +331,11 @@ static inline unsigned grid_for(uint64_t n, unsigned per_block, unsigned cap = 0
 cellector_status launch_alpha_beta(cellector_ctx *c)
 {
     const uint64_t L = c->L;
+    const uint32_t n_work = c->tile_work ? 3u * CELLECTOR_TILE_WORK_STRIDE : 0u;
     hipLaunchKernelGGL(k_alpha_beta, dim3(grid_for(L, 256)), dim3(256), 0, c->stream, L, c->s_alt, c->s_ref,
-                       c->x_locus + LB_ALT_MIN * L, c->x_locus + LB_REF_MIN * L, c->mask, c->ab);
+                       c->x_locus + LB_ALT_MIN * L, c->x_locus + LB_REF_MIN * L, c->mask, c->ab,
+                       c->x_locus + (uint64_t)LB_PLANES * L, c->d_counters, c->tile_work, n_work);
+    c->work_zeroed = n_work != 0;
     HIPCHK(c, hipGetLastError());
     return CELLECTOR_OK;
 }
@@ -384,6 +405,14 @@ cellector_status launch_locus_filter(cellector_ctx *c)
     if (c->L == 0) return CELLECTOR_OK;
     hipLaunchKernelGGL(k_locus_filter, dim3(grid_for(c->L, 256)), dim3(256), 0, c->stream, c->L, c->x_locus, c->mask,
                        c->mask_next, c->d_counters);
+    HIPCHK(c, hipGetLastError());
+    return CELLECTOR_OK;
+}
+
+cellector_status launch_iter_summary(cellector_ctx *c)
+{
+    hipLaunchKernelGGL(k_iter_summary, dim3(1), dim3(64), 0, c->stream, c->x_locus + (uint64_t)LB_PLANES * c->L, c->d_counters,
+                       c->sel_out + 8, c->h_sum_dev);
     HIPCHK(c, hipGetLastError());
     return CELLECTOR_OK;
 }

@@ -1446,7 +1446,9 @@ static cellector_status run_tile_pass(cellector_ctx *c, int set, bool expected)
     if (per_group > n_cols) per_group = n_cols;
     const dim3 grid(per_group * c->t_groups);
     uint32_t *work = c->tile_work + (size_t)set * T_GROUPS_MAX;
-    HIPCHK(c, hipMemsetAsync(work, 0, T_GROUPS_MAX * sizeof(uint32_t), c->stream));
+    static_assert(T_GROUPS_MAX == CELLECTOR_TILE_WORK_STRIDE, "k_alpha_beta resets the counters with this stride");
+    if (!(set == 0 && c->work_zeroed))  // else: reset by this iteration's k_alpha_beta
+        HIPCHK(c, hipMemsetAsync(work, 0, T_GROUPS_MAX * sizeof(uint32_t), c->stream));
     timer_begin(c, CELLECTOR_K_TILE_LL);
 #define LAUNCH_TILE(E, S)                                                                                                  \
     hipLaunchKernelGGL((k_tile_ll<E, S>), grid, dim3(T_THREADS), 0, c->stream, c->t_nb, c->t_nj, c->t_cpg, c->t_groups, n_cols, \
