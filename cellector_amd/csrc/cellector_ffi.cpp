@@ -114,7 +114,7 @@ cellector_status cellector_create(cellector_ctx **out, int device_id)
     bool ok = hipMalloc((void **)&c->lf, sizeof lf) == hipSuccess &&
               hipMemcpy(c->lf, lf, sizeof lf, hipMemcpyHostToDevice) == hipSuccess &&
               hipMalloc((void **)&c->d_counters, 8 * sizeof(uint32_t)) == hipSuccess &&
-              hipMalloc((void **)&c->sel_hist, SEL_T * 256 * sizeof(uint32_t)) == hipSuccess &&
+              hipMalloc((void **)&c->sel_hist, 3 * SEL_T * 256 * sizeof(uint32_t)) == hipSuccess &&
               hipMalloc((void **)&c->sel_state, 4 * SEL_T * sizeof(uint64_t)) == hipSuccess &&
               hipMalloc((void **)&c->sel_out, 16 * sizeof(double)) == hipSuccess &&
               hipHostMalloc((void **)&c->h_sel, 32 * sizeof(double)) == hipSuccess &&

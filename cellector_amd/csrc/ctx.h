@@ -136,8 +136,8 @@ struct cellector_ctx {
                                      // 2 = minority-driven tally over the by-cell CSR
 
     // order-statistic workspace
-    uint32_t *sel_hist = nullptr;   // [SEL_T][256]
-    uint64_t *sel_state = nullptr;  // [SEL_T][2] prefix, remaining rank; then the ticket counter
+    uint32_t *sel_hist = nullptr;   // [3][SEL_T][256] rotating: previous / this / next pass
+    uint64_t *sel_state = nullptr;  // [2][SEL_T][2] prefix, remaining rank of the previous / this pass
     double *sel_out = nullptr;      // [16] device: [0..5] order statistics, [8..10] median, iqr, threshold
     double *h_sel = nullptr;        // pinned [32]: iteration summary written by k_iter_summary, read in em_finish
     double *h_sum_dev = nullptr;    // the device's address of h_sel
@@ -206,7 +206,6 @@ cellector_status launch_posteriors(cellector_ctx *c, double mf0, double lp_min, 
                                    double lp_dbl);
 cellector_status launch_final_tallies(cellector_ctx *c, uint64_t *d_out /*[4*total_loci]*/);
 // order statistics: exact values at SEL_T 0-based ranks of n keys
-cellector_status select_ranks(cellector_ctx *c, const double *keys, uint64_t n, const uint64_t ranks[SEL_T]);
 cellector_status select_threshold(cellector_ctx *c, const double *keys, uint64_t n, double iqr_multiple);
 // ingest
 cellector_status ingest_stage_host_coo(cellector_ctx *c, uint64_t nnz, const uint32_t *locus0,
