@@ -207,14 +207,25 @@ __global__ __launch_bounds__(T_THREADS, 4) void k_tile_ll(uint32_t nb, uint32_t 
 #endif
     // lookup of entry KK of the row = u16 number KK + 1 = half (KK + 1) & 1 of dword (KK + 1) >> 1.  The slice's K is odd
     // and wave-uniform, so the lookups come in pairs behind one scalar branch.
-#define TILE_LK(KK)                                                                                              \
+#define TILE_RD(V, KK)                                                                                           \
+    tab_t V;                                                                                                     \
     do {                                                                                                         \
         const uint32_t idx__ = (((KK) + 1) & 1) ? (w__[((KK) + 1) >> 1] >> 16) : (w__[((KK) + 1) >> 1] & 0xffffu); \
-        tab_t v__;                                                                                               \
-        TILE_LOOKUP(v__, idx__);                                                                                 \
-        if constexpr (EXPECTED) { a_ll__ += v__.x; a_el__ += v__.y; }                                            \
-        else a_ll__ += v__;                                                                                      \
+        TILE_LOOKUP(V, idx__);                                                                                   \
     } while (0)
+#define TILE_ADD(V)                                                                                              \
+    do {                                                                                                         \
+        if constexpr (EXPECTED) { a_ll__ += (V).x; a_el__ += (V).y; }                                            \
+        else a_ll__ += (V);                                                                                      \
+    } while (0)
+    // one level of the written-out lookup chain: request the next pair, THEN add the pair requested one level earlier (the
+    // sums still run in entry order), so that four lookups of a wave are in flight instead of two
+#define TILE_LEVEL(KA, KB, PA, PB, BODY)                                                                         \
+    if (K__ > (KA)) {                                                                                            \
+        TILE_RD(v##KA, KA); TILE_RD(v##KB, KB);                                                                  \
+        TILE_ADD(PA); TILE_ADD(PB);                                                                              \
+        BODY                                                                                                     \
+    } else { TILE_ADD(PA); TILE_ADD(PB); }
 #define TILE_STEP(S, E, H)                                                                                       \
     do {                                                                                                         \
         /* 1. consume the row requested two steps ago: u16 number i of the row sits in half i & 1 of dword i >> 1 */ \
@@ -225,30 +236,32 @@ __global__ __launch_bounds__(T_THREADS, 4) void k_tile_ll(uint32_t nb, uint32_t 
         /* 2. issue the next requests: rows of step t+2 (their header is here), header of step t+4 */            \
         ROW_LOAD(E, H);                                                                                          \
         HDR_LOAD(H, t + 4);                                                                                      \
-        /* 3. this lane's cell of the slice: K lookups for every lane (padding entries hit the zero row) */      \
+        /* 3. the cell's accumulator is requested first (LDS answers in order: it has landed when the sums are done), */ \
+        /*    then this lane's cell of the slice: K lookups for every lane (padding entries hit the zero row) */  \
+        tab_t acc__ = s_acc[(S) * T_BC + cell__];                                                                \
         double a_ll__ = 0.0, a_el__ = 0.0;                                                                       \
         /* (written out: a loop with an early exit gets re-rolled and then selects its register at run time) */  \
-        TILE_LK(0);                                                                                              \
-        if (K__ > 1) { TILE_LK(1); TILE_LK(2);                                                                   \
-        if (K__ > 3) { TILE_LK(3); TILE_LK(4);                                                                   \
-        if (K__ > 5) { TILE_LK(5); TILE_LK(6);                                                                   \
-        if (K__ > 7) { TILE_LK(7); TILE_LK(8);                                                                   \
-        if (K__ > 9) { TILE_LK(9); TILE_LK(10);                                                                  \
-        if (K__ > 11) { TILE_LK(11); TILE_LK(12);                                                                \
-        if (K__ > 13) { TILE_LK(13); TILE_LK(14);                                                                \
-        for (uint32_t k = T_NE; k < K__; k++) { /* rare: a slice with more than T_NE entries per cell */         \
-            const tab_t v__ = s_tab[cur__[k + 1]];                                                               \
-            if constexpr (EXPECTED) { a_ll__ += v__.x; a_el__ += v__.y; }                                        \
-            else a_ll__ += v__;                                                                                  \
-        } } } } } } } }                                                                                          \
+        TILE_RD(v0, 0);                                                                                          \
+        if (K__ > 1) {                                                                                           \
+            TILE_RD(v1, 1); TILE_RD(v2, 2);                                                                      \
+            TILE_ADD(v0);                                                                                        \
+            TILE_LEVEL(3, 4, v1, v2,                                                                             \
+            TILE_LEVEL(5, 6, v3, v4,                                                                             \
+            TILE_LEVEL(7, 8, v5, v6,                                                                             \
+            TILE_LEVEL(9, 10, v7, v8,                                                                            \
+            TILE_LEVEL(11, 12, v9, v10,                                                                          \
+            TILE_LEVEL(13, 14, v11, v12,                                                                         \
+                TILE_ADD(v13); TILE_ADD(v14);                                                                    \
+                for (uint32_t k = T_NE; k < K__; k++) { /* rare: a slice with more than T_NE entries per cell */ \
+                    const tab_t v__ = s_tab[cur__[k + 1]];                                                       \
+                    TILE_ADD(v__);                                                                               \
+                } ))))))                                                                                         \
+        } else TILE_ADD(v0);                                                                                     \
         /* 4. add the tile's sums to the cell's accumulator (one lane per cell and tile; tiles of the same block */ \
         /*    are separated by the chunk barriers).  A read and a write: two ds_add_f64 measured 15 % slower.      */ \
-        {                                                                                                        \
-            tab_t a__ = s_acc[(S) * T_BC + cell__];                                                              \
-            if constexpr (EXPECTED) { a__.x += a_ll__; a__.y += a_el__; }                                        \
-            else a__ += a_ll__;                                                                                  \
-            s_acc[(S) * T_BC + cell__] = a__;                                                                    \
-        }                                                                                                        \
+        if constexpr (EXPECTED) { acc__.x += a_ll__; acc__.y += a_el__; }                                        \
+        else acc__ += a_ll__;                                                                                    \
+        s_acc[(S) * T_BC + cell__] = acc__;                                                                      \
         t++;                                                                                                     \
     } while (0)
 
@@ -295,7 +308,9 @@ __global__ __launch_bounds__(T_THREADS, 4) void k_tile_ll(uint32_t nb, uint32_t 
     __builtin_amdgcn_s_waitcnt(0);  // the pipeline's last (clamped, unused) loads have landed before the registers are reused
   }
 #undef TILE_STEP
-#undef TILE_LK
+#undef TILE_LEVEL
+#undef TILE_ADD
+#undef TILE_RD
 #undef TILE_LOOKUP
 #undef ROW_LOAD
 #undef HDR_LOAD
@@ -572,10 +587,11 @@ __global__ void k_pack_flag_bits(uint64_t n, const uint8_t *__restrict__ flags, 
 // Form of the locus pass, decided on the device from this shard's exclusion-set size (see k_minority_hist below)
 #define LM_NUM 1  // minority-driven when n_min / nloc <= LM_NUM / LM_DEN
 #define LM_DEN 8
-// (n_sub = partial planes of the minority-driven form: its 16-bit LDS counters hold a subset of at most 65535 cells)
+// (n_sub = partial planes of the minority-driven form: its 16-bit LDS counters hold a subset of at most 32767 cells — half
+// the range, so that even a file that lists every (locus, cell) pair twice cannot carry into the neighbouring counter)
 __device__ __forceinline__ bool locus_by_minority(int mode, uint32_t n_min, uint64_t nloc, uint32_t n_sub)
 {
-    if ((uint64_t)n_min > (uint64_t)n_sub * 65535u) return false;
+    if ((uint64_t)n_min > (uint64_t)n_sub * 32767u) return false;
     return mode == 2 || (mode == 0 && (uint64_t)n_min * LM_DEN <= nloc * LM_NUM);
 }
 
@@ -780,7 +796,7 @@ __global__ __launch_bounds__(LR_THREADS) void k_minority_ranges(int locus_mode, 
     const uint32_t n_min = *n_min_p;
     if (!locus_by_minority(locus_mode, n_min, nloc, n_sub)) return;
     // u16 counters, two per word, code-major: the bank of a counter follows the locus (spread out), not the code (most
-    // entries are single reads: codes 0 and 1).  A subset has at most 65535 cells (locus_by_minority): no carry.
+    // entries are single reads: codes 0 and 1).  A subset has at most 32767 cells (locus_by_minority): no carry.
     __shared__ uint32_t s_hist[T_NCODE * LR_ROW / 2];
     __shared__ uint64_t s_beg[LR_THREADS];
     __shared__ uint32_t s_len[LR_THREADS];
