@@ -725,6 +725,16 @@ __global__ __launch_bounds__(LS_THREADS) void k_locus_stats2(uint64_t L, uint32_
 #define LR_GROUP 64      // lanes per (cell, range) segment: ~41 entries at 1 % density (a tail loop would serialise)
 #define LR_ROW (LR_LOCI + 2)  // u16 counters per code row (even: a row starts on a word)
 
+// compact by-cell entries for k_minority_ranges: locus | code << 28 (code 15: an overflow entry, not counted there) —
+// half the bytes of the packed CSR entry, and that kernel runs at the memory rate
+__global__ __launch_bounds__(256) void k_cell_compact(uint64_t nnz, const uint64_t *__restrict__ csr_ent, uint32_t *__restrict__ c4r)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= nnz) return;
+    const uint64_t e = csr_ent[i];
+    c4r[i] = ENT_IDX(e) | ((ent_regular(e) ? ent_code(e) : 15u) << 28);
+}
+
 // roff[cell][r] = number of the row's entries with locus < r * LR_LOCI, r = 0..R (row sorted by locus).  Wave per row.
 __global__ __launch_bounds__(256) void k_range_offsets(uint64_t n_rows, uint32_t R, const uint64_t *__restrict__ csr_ptr,
                                                        const uint64_t *__restrict__ csr_ent, uint32_t *__restrict__ roff)
@@ -790,7 +800,7 @@ __global__ __launch_bounds__(LR_THREADS) void k_minority_ranges(int locus_mode, 
                                                                const uint32_t *__restrict__ n_min_p,
                                                                const uint32_t *__restrict__ mroff,
                                                                const uint64_t *__restrict__ mbeg,
-                                                               const uint64_t *__restrict__ csr_ent,
+                                                               const uint32_t *__restrict__ c4r,
                                                                uint32_t *__restrict__ hist_min /*[n_sub][L][16]*/)
 {
     const uint32_t n_min = *n_min_p;
@@ -809,8 +819,8 @@ __global__ __launch_bounds__(LR_THREADS) void k_minority_ranges(int locus_mode, 
     const uint32_t grp = lane / LR_GROUP, gl = lane % LR_GROUP;
 #define LR_COUNT(E)                                                                                              \
     do {                                                                                                         \
-        if (ent_regular(E)) {                                                                                    \
-            const uint32_t idx__ = ent_code(E) * LR_ROW + (ENT_IDX(E) - l0);                                     \
+        if (((E) >> 28) < (uint32_t)T_NCODE) {                                                                   \
+            const uint32_t idx__ = ((E) >> 28) * LR_ROW + (((E) & 0x0fffffffu) - l0);                            \
             atomicAdd(&s_hist[idx__ >> 1], 1u << ((idx__ & 1u) * 16u));                                          \
         }                                                                                                        \
     } while (0)
@@ -839,11 +849,11 @@ __global__ __launch_bounds__(LR_THREADS) void k_minority_ranges(int locus_mode, 
         constexpr int SPW = 64 / LR_GROUP;  // segments per wave load
         constexpr int NQ = 16;
         for (uint32_t q0 = 0; q0 < 64 / SPW; q0 += NQ) {
-            uint64_t e[NQ];
+            uint32_t e[NQ];
 #pragma unroll
             for (int u = 0; u < NQ; u++) {
                 const uint32_t seg = wv * 64 + (q0 + u) * SPW + grp;
-                e[u] = gl < s_len[seg] ? csr_ent[s_beg[seg] + gl] : 0;  // 0: alt + ref == 0, not regular
+                e[u] = gl < s_len[seg] ? c4r[s_beg[seg] + gl] : ~0u;  // all ones: code 15, not counted
             }
 #pragma unroll
             for (int u = 0; u < NQ; u++) LR_COUNT(e[u]);
@@ -852,7 +862,7 @@ __global__ __launch_bounds__(LR_THREADS) void k_minority_ranges(int locus_mode, 
                 const uint32_t sn = s_len[seg];
                 const uint64_t sb = s_beg[seg];
                 for (uint32_t j = gl + LR_GROUP; j < sn; j += LR_GROUP) {
-                    const uint64_t x = csr_ent[sb + j];
+                    const uint32_t x = c4r[sb + j];
                     LR_COUNT(x);
                 }
             }
@@ -1221,7 +1231,7 @@ void tiled_free(cellector_ctx *c)
     dev_free(c->c4_ptr); dev_free(c->c4_ent); dev_free(c->ovc_ptr); dev_free(c->ovc_ent);
     dev_free(c->hist_all); dev_free(c->tab); dev_free(c->part); dev_free(c->ab3);
     dev_free(c->masked_cnt); dev_free(c->flag_bits); dev_free(c->ovf_perm); dev_free(c->ovf_val); dev_free(c->ovf_tab);
-    dev_free(c->ovf_sum); dev_free(c->ovf_lp); dev_free(c->ovc_locus); dev_free(c->ovf_nmask); dev_free(c->tile_work); dev_free(c->minlist); dev_free(c->hist_min); dev_free(c->roff); dev_free(c->mroff); dev_free(c->mbeg);
+    dev_free(c->ovf_sum); dev_free(c->ovf_lp); dev_free(c->ovc_locus); dev_free(c->ovf_nmask); dev_free(c->tile_work); dev_free(c->minlist); dev_free(c->hist_min); dev_free(c->roff); dev_free(c->c4r); dev_free(c->mroff); dev_free(c->mbeg);
     c->mroff_cap = 0;
     c->tiled_ready = false;
     c->ovf_n = 0; c->n_masked_loci = 0;
@@ -1231,6 +1241,7 @@ cellector_status tiled_build(cellector_ctx *c)
 {
     const uint64_t nloc = c->nloc, L = c->L;
     if (nloc >= (1ull << 28)) return ctx_fail(c, CELLECTOR_EINVAL, "tiled engine: more than 2^28 cells per shard");
+    if (L >= (1ull << 28)) return ctx_fail(c, CELLECTOR_EINVAL, "tiled engine: more than 2^28 loci");
     c->t_nb = (uint32_t)((nloc + T_BC - 1) / T_BC);
     c->t_nj = (uint32_t)((L + T_BL - 1) / T_BL);
     if (c->t_nb == 0) c->t_nb = 1;
@@ -1365,6 +1376,10 @@ cellector_status tiled_build(cellector_ctx *c)
         c->lr_sub = sub;
         CHK(dev_alloc(c, &c->hist_min, (uint64_t)sub * L * 16));
         CHK(dev_alloc(c, &c->roff, nloc * (R + 1)));
+        CHK(dev_alloc(c, &c->c4r, c->nnz));
+        if (c->nnz)
+            hipLaunchKernelGGL(k_cell_compact, dim3(gcap(c->nnz, 256, 0x7fffffffu)), dim3(256), 0, c->stream, c->nnz, c->csr_ent,
+                               c->c4r);
         if (nloc)
             hipLaunchKernelGGL(k_range_offsets, dim3(gcap(nloc, 4)), dim3(256), 0, c->stream, nloc, R, c->csr_ptr, c->csr_ent,
                                c->roff);
@@ -1569,7 +1584,7 @@ cellector_status tiled_locus_pass(cellector_ctx *c)
         hipLaunchKernelGGL(k_minority_offsets, dim3(gcap(want, LT_CELLS, 0x7fffffffu)), dim3(256), lds_t, c->stream, c->locus_mode,
                            c->nloc, c->lr_sub, R, c->mroff_cap, c->d_counters + DC_N_MIN, c->minlist, c->csr_ptr, c->roff, c->mroff, c->mbeg);
         hipLaunchKernelGGL(k_minority_ranges, dim3(R * c->lr_sub), dim3(LR_THREADS), 0, c->stream, c->locus_mode, c->nloc, c->L, R,
-                           c->lr_sub, c->mroff_cap, c->d_counters + DC_N_MIN, c->mroff, c->mbeg, c->csr_ent, c->hist_min);
+                           c->lr_sub, c->mroff_cap, c->d_counters + DC_N_MIN, c->mroff, c->mbeg, c->c4r, c->hist_min);
     }
     hipLaunchKernelGGL(k_locus_finalize, dim3(gcap(c->L * LF_LANES, 256, 0x7fffffffu)), dim3(256), 0, c->stream, c->L, c->locus_mode,
                        c->nloc, c->lr_sub, c->d_counters + DC_N_MIN, c->hist_min, c->flag_bits, c->hist_all, c->tab_em,
