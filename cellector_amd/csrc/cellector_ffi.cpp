@@ -121,7 +121,8 @@ cellector_status cellector_create(cellector_ctx **out, int device_id)
               hipHostGetDevicePointer((void **)&c->h_sum_dev, c->h_sel, 0) == hipSuccess &&
               create_side_stream(&c->side) &&
               hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) == hipSuccess &&
-              hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) == hipSuccess;
+              hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) == hipSuccess &&
+              hipEventCreateWithFlags(&c->ev_join2, hipEventDisableTiming) == hipSuccess;
     if (!ok) {
         cellector_destroy(c);
         return CELLECTOR_EDEVICE;
@@ -142,6 +143,7 @@ void cellector_destroy(cellector_ctx *c)
     if (c->side) (void)hipStreamDestroy(c->side);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->ev_join2) (void)hipEventDestroy(c->ev_join2);
     delete c;
 }
 
@@ -160,10 +162,7 @@ cellector_status cellector_set_option(cellector_ctx *c, const char *key, int64_t
     if (!strcmp(key, "compute_expected")) c->compute_expected = v != 0;
     else if (!strcmp(key, "timing")) c->timing = v != 0;
     else if (!strcmp(key, "keep_coo")) c->keep_coo = v != 0;
-    else if (!strcmp(key, "overlap")) {
-        if (v < 0 || v > 2) return ctx_fail(c, CELLECTOR_EINVAL, "overlap must be 0, 1 or 2");
-        c->overlap = (int)v;
-    }
+    else if (!strcmp(key, "overlap")) c->overlap = v != 0;
     else if (!strcmp(key, "locus_mode")) {
         if (v < 0 || v > 2) return ctx_fail(c, CELLECTOR_EINVAL, "locus_mode must be 0 (automatic), 1 (stream) or 2 (minority-driven)");
         c->locus_mode = (int)v;
@@ -440,7 +439,7 @@ cellector_status cellector_em_begin(cellector_ctx *c)
     CHK(launch_alpha_beta(c));
     if (c->nloc != c->total_cells)  // other shards' slices must be zero before the sum-exchange
         HIPCHK(c, hipMemsetAsync(c->x_norm, 0, c->total_cells * 8, c->stream));
-    cellector_status st = c->engine == 2 ? tiled_cell_pass(c, c->ab, c->x_norm + c->cell_begin)
+    cellector_status st = c->engine == 2 ? tiled_cell_pass(c, c->ab, c->x_norm + c->cell_begin, true)
                                          : launch_cell_ll(c, c->ab, c->x_norm + c->cell_begin);
     c->work_zeroed = false;  // (only this iteration's first tile pass may rely on k_alpha_beta's reset)
     CHK(st);
@@ -591,7 +590,7 @@ cellector_status cellector_cell_log_likelihoods(cellector_ctx *c, const double *
     SETDEV(c);
     CHK(launch_ab_from_host(c, alpha, beta, mask));
     // the tiled engine derives the used-locus count from the ctx's own mask; with a caller mask use the CSR kernel
-    if (c->engine == 2 && !mask && c->n_masked_loci == 0) CHK(tiled_cell_pass(c, c->ab, nullptr));
+    if (c->engine == 2 && !mask && c->n_masked_loci == 0) CHK(tiled_cell_pass(c, c->ab, nullptr, false));
     else CHK(launch_cell_ll(c, c->ab, nullptr));
     const size_t b = c->nloc * 8;
     if (ll) CHK(d2h(c, ll, c->ll, b));

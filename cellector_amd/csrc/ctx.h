@@ -44,9 +44,8 @@ struct cellector_ctx {
     hipStream_t stream = nullptr;
     // side stream for the small overflow kernels that run next to the tile kernel (fork/join with events)
     hipStream_t side = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    int overlap = 2;  // option "overlap": overflow kernels on the side stream next to the tile kernel: 2 = the whole chain,
-                      // 1 = only the per-cell gather (tables and values in front), 0 = nothing
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr;
+    int overlap = 1;  // option "overlap": 1 = the overflow kernels run on the side stream next to the tile kernel, 0 = in front
     mutable std::string err;
 
     // options
@@ -105,11 +104,13 @@ struct cellector_ctx {
     int tab_em_stride = 1;           // 2 when that table holds (log-pmf, expected) pairs
     uint64_t *ovf_ptr = nullptr, *ovf_ent = nullptr;    // overflow CSR (alt+ref == 0 or > 4), packed like csr_ent
     uint64_t ovf_n = 0;
-    uint32_t *ovf_perm = nullptr;    // [ovf_n] by-cell position -> by-locus position
     double *ovf_tab = nullptr;       // [L][128] per-locus cumulative-log / expected tables for overflow entries
-    double2 *ovf_val = nullptr;      // [3][ovf_n] (log-pmf, expected term) of overflow entries, by-locus order
+    double *ovf_etab = nullptr;      // [L][4] E(n), n = 5..8: compact copy for the cell side
+    bool ovf_locus_pending = false;  // the side stream still owes this iteration's ovf_lp (event ev_join2)
     double *ovf_lp = nullptr;        // [ovf_n] the EM pass' overflow log-pmfs alone, by-locus order (locus pass)
     double *ovf_sum = nullptr;       // [3][2][nloc] per-cell sums of the overflow values (ll, expected) per table set
+    uint32_t *ovf_slow_rows = nullptr;  // [ovf_n_slow] rows with an overflow entry whose alt+ref exceeds the E tables
+    uint32_t ovf_n_slow = 0;
     uint32_t *ovc_locus = nullptr;   // [ovf_n] compact locus index of every overflow entry, by-locus order
     uint32_t *ovf_nmask = nullptr;   // [L] which alt+ref totals (4..17) occur among the locus' overflow entries
     uint64_t *c4_ptr = nullptr;      // [L+1] compact CSC of regular entries
@@ -222,7 +223,7 @@ cellector_status dev_sort_pairs_u32_u64(cellector_ctx *c, uint32_t *keys_in, uin
 // engine v2 (kernels_tiled.hip)
 cellector_status tiled_build(cellector_ctx *c);
 void tiled_free(cellector_ctx *c);
-cellector_status tiled_cell_pass(cellector_ctx *c, const double2 *ab, double *norm_out);
+cellector_status tiled_cell_pass(cellector_ctx *c, const double2 *ab, double *norm_out, bool for_em);
 cellector_status tiled_locus_pass(cellector_ctx *c);
 cellector_status tiled_masked_update(cellector_ctx *c);
 cellector_status tiled_posteriors(cellector_ctx *c, double mf0, double lp_min, double lp_maj, double lp_dbl);

@@ -318,10 +318,14 @@ __global__ __launch_bounds__(T_THREADS, 4) void k_tile_ll(uint32_t nb, uint32_t 
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// overflow entries (n == 0 or n > 3).  Their log-pmf / expected term are evaluated once per pass in LOCUS-major
-// order (k_ovf_values: alpha/beta wave-uniform, so ln B-ratios come from per-locus cumulative log tables held in
-// registers and fetched by cross-lane shuffles), stored as double2 per entry, and then only GATHERED: by the cell
-// side through a precomputed permutation (k_ovf_cell_sums) and by the locus pass directly (k_locus_stats2).
+// overflow entries (alt+ref == 0 or > T_K; 0.8 % at cfg4).  Two consumers, two evaluations:
+//   cell side   k_ovf_cell_direct: a thread per cell row evaluates the row's overflow entries itself from (alpha, beta) of
+//               their loci (a gather out of an L x 16 B table that stays in L2) and takes the expected terms from a compact
+//               E table (k_ovf_tables_e).  Runs on the side stream beside the tile kernel.
+//   locus side  the locus pass needs every overflow entry's log-pmf in by-locus order: k_ovf_tables (per-locus cumulative
+//               log tables) + k_ovf_values (a thread per entry: lnC + LA[alt] + LB[ref] - LAB[n]) write them to ovf_lp.
+//               Only the EM pass needs them, and only at the locus finalize: they follow the cell side on the side stream
+//               and run beside the end of the tile kernel, the order statistics and the minority kernels.
 // ---------------------------------------------------------------------------------------------------------
 #define OV_NT 18  // cumulative tables cover counts 0..17; larger counts take the generic device_math path
 #define OV_NE 17  // expected terms E(n) tabulated for n = 4..17
@@ -388,7 +392,8 @@ __global__ __launch_bounds__(256) void k_ovf_tables(uint64_t L, const double2 *_
     }
 }
 __global__ __launch_bounds__(256) void k_ovf_tables_e(uint64_t L, const double2 *__restrict__ ab,
-                                                      const uint32_t *__restrict__ nmask, double *__restrict__ otab)
+                                                      const uint32_t *__restrict__ nmask, double *__restrict__ otab,
+                                                      double *__restrict__ etab /*[L][4]: E(5..8), the cell side's compact copy*/)
 {
     const uint64_t idx = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     const uint64_t l = idx >> 4;  // 16 slots per locus, 14 used
@@ -397,25 +402,24 @@ __global__ __launch_bounds__(256) void k_ovf_tables_e(uint64_t L, const double2 
     if (i > (uint32_t)OV_NE - 4u || !((nmask[l] >> i) & 1u)) return;
     const double2 p = ab[l];
     if (!(p.x >= 0.0)) return;
-    otab[l * OV_ROW + OV_EOFF + i] = ov_expected_rec(p.x, p.y, 4u + i);
+    const double e = ov_expected_rec(p.x, p.y, 4u + i);
+    otab[l * OV_ROW + OV_EOFF + i] = e;
+    if (i >= 1 && i <= 4) etab[l * 4 + (i - 1)] = e;
 }
 
-// one thread per overflow entry, by-locus order: neighbouring threads share a locus, so the four table words an entry
-// needs (LA[alt], LB[ref], LAB[n], E(n) of its locus' row) come out of L1; no per-locus loop, no cross-lane traffic
-template <bool EXPECTED>
+// one thread per overflow entry, by-locus order: neighbouring threads share a locus, so the three table words an entry
+// needs (LA[alt], LB[ref], LAB[n] of its locus' row) come out of L1; no per-locus loop, no cross-lane traffic
 __global__ __launch_bounds__(256) void k_ovf_values(uint64_t n_ovf, const uint32_t *__restrict__ ovc_locus,
                                                     const uint64_t *__restrict__ ovc_ent,
-                                                    const double2 *__restrict__ ab, const double *__restrict__ lf_g,
-                                                    const double *__restrict__ otab, double2 *__restrict__ val,
-                                                    double *__restrict__ lp_only /*may be null: the locus pass' copy*/)
+                                                    const double2 *__restrict__ ab, const double *__restrict__ lf,
+                                                    const double *__restrict__ otab, double *__restrict__ lp_out)
 {
-    const double *lf = lf_g;  // 1.4 KB: L1-resident (a per-block copy in LDS costs a load + barrier before any work)
     const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n_ovf) return;
     const uint32_t l = ovc_locus[i];
     const uint64_t en = ovc_ent[i];
     const double *row = otab + (uint64_t)l * OV_ROW;
-    double lp = 0.0, ee = 0.0;
+    double lp = 0.0;
     if (row[0] >= 0.0) {  // else a masked locus: no PMFData (main.rs:556)
         const uint32_t a = ENT_ALT(en), r = ENT_REF(en), n = a + r;
         if (n == 0) lp = 0.0;  // quirk Q14: exactly zero
@@ -424,16 +428,8 @@ __global__ __launch_bounds__(256) void k_ovf_values(uint64_t n_ovf, const uint32
             const double2 p = ab[l];
             lp = ov_slow_log_pmf(lf, p.x, p.y, a, r);
         }
-        if (EXPECTED && n != 0) {
-            if (n >= 4 && n <= (uint32_t)OV_NE) ee = row[OV_EOFF + (n - 4)];
-            else {
-                const double2 p = ab[l];
-                ee = ov_slow_expected(lf, p.x, p.y, n);
-            }
-        }
     }
-    val[i] = make_double2(lp, ee);
-    if (lp_only) lp_only[i] = lp;  // the locus pass streams this: half the bytes of the pairs
+    lp_out[i] = lp;
 }
 
 // locus of every overflow entry (by-locus order): wave per locus
@@ -443,31 +439,6 @@ __global__ __launch_bounds__(256) void k_ovf_locus_ids(uint64_t L, const uint64_
     const uint64_t wave0 = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (uint64_t)gridDim.x * 4;
     for (uint64_t l = wave0; l < L; l += nwaves)
         for (uint64_t i = ovc_ptr[l] + lane; i < ovc_ptr[l + 1]; i += 64) ovc_locus[i] = (uint32_t)l;
-}
-
-// perm[position in the by-cell overflow array] = position in the by-locus overflow array
-__global__ __launch_bounds__(256) void k_ovf_perm(uint64_t L, const uint64_t *__restrict__ ovc_ptr,
-                                                  const uint64_t *__restrict__ ovc_ent,
-                                                  const uint64_t *__restrict__ ovf_ptr,
-                                                  const uint64_t *__restrict__ ovf_ent, uint32_t *__restrict__ perm)
-{
-    const int lane = threadIdx.x & 63;
-    const uint64_t wave0 = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (uint64_t)gridDim.x * 4;
-    for (uint64_t l = wave0; l < L; l += nwaves) {
-        const uint64_t beg = ovc_ptr[l], end = ovc_ptr[l + 1];
-        for (uint64_t i = beg + lane; i < end; i += 64) {
-            const uint32_t cell = ENT_IDX(ovc_ent[i]);
-            uint64_t lo = ovf_ptr[cell], hi = ovf_ptr[cell + 1];
-            while (lo < hi) {
-                const uint64_t mid = (lo + hi) >> 1;
-                if (ENT_IDX(ovf_ent[mid]) < (uint32_t)l) lo = mid + 1; else hi = mid;
-            }
-            // duplicate (locus, cell) lines of a malformed file sit next to each other in both orders
-            uint64_t d = 0;
-            while (i - d > beg && ENT_IDX(ovc_ent[i - d - 1]) == cell) d++;
-            perm[lo + d] = (uint32_t)i;
-        }
-    }
 }
 
 // nmask[l]: bit (n - 4) set iff an overflow entry of locus l has alt+ref == n, 4 <= n <= OV_NE (static)
@@ -489,32 +460,73 @@ __global__ __launch_bounds__(256) void k_ovf_nmask(uint64_t L, const uint64_t *_
     }
 }
 
-// cell side of the overflow entries: one THREAD per cell row sums the row's overflow values in ascending-locus order
-// through the permutation (sequential: deterministic and independent of the sharding).  Runs on the side stream next
-// to the tile kernel; k_cell_finalize adds the result to the tile partials.
+// cell side of the overflow entries: a thread per cell row evaluates them itself from (alpha, beta) of their loci (a 16-byte
+// gather out of a table of L x 16 B that stays in L2) — one log of a ratio of short products per entry — in ascending-locus
+// order (sequential: deterministic), and takes the expected terms from the compact E table.  The row's 8-byte entries are
+// all the HBM traffic; gathering stored per-entry values instead fetched a 128-byte line per entry (2.3 GB at cfg4 for
+// 0.26 GB of values) and slowed the tile kernel beside it more.  k_cell_finalize adds the result to the tile partials.
+// (48 VGPRs and no calls: the persistent tile workgroups leave 96 VGPRs per SIMD, so two waves of this kernel fit beside
+// them on every SIMD; the entry loop is not unrolled — a row has ~16 overflow entries and hundreds of thousands of rows
+// are in flight.  The one rare case that needs the long log-space fold — the expected term of a total above OV_NE — is
+// left to k_ovf_cell_slow_e, which visits only the rows that have such an entry.)
 template <bool EXPECTED>
-__global__ __launch_bounds__(256) void k_ovf_cell_sums(uint64_t n_rows, const uint64_t *__restrict__ ovf_ptr,
-                                                       const uint32_t *__restrict__ perm,
-                                                       const double2 *__restrict__ val, double *__restrict__ o_ll,
-                                                       double *__restrict__ o_ell)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(48))) void k_ovf_cell_direct(
+    uint64_t n_rows, const uint64_t *__restrict__ ovf_ptr, const uint64_t *__restrict__ ovf_ent,
+    const double2 *__restrict__ ab, const double *__restrict__ lf, const double *__restrict__ etab,
+    const double *__restrict__ otab, double *__restrict__ o_ll, double *__restrict__ o_ell)
 {
     const uint64_t row = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (row >= n_rows) return;
     double s = 0.0, e = 0.0;
-    const uint64_t beg = ovf_ptr[row], end = ovf_ptr[row + 1];
-    uint64_t i = beg;
-    for (; i + 4 <= end; i += 4) {  // four independent gathers in flight
-        const double2 v0 = val[perm[i]], v1 = val[perm[i + 1]], v2 = val[perm[i + 2]], v3 = val[perm[i + 3]];
-        s += v0.x; s += v1.x; s += v2.x; s += v3.x;
-        if (EXPECTED) { e += v0.y; e += v1.y; e += v2.y; e += v3.y; }
-    }
-    for (; i < end; i++) {
-        const double2 v = val[perm[i]];
-        s += v.x;
-        if (EXPECTED) e += v.y;
+    const uint64_t end = ovf_ptr[row + 1];
+#pragma unroll 1
+    for (uint64_t i = ovf_ptr[row]; i < end; i++) {
+        const uint64_t en = ovf_ent[i];
+        const uint32_t l = ENT_IDX(en), a = ENT_ALT(en), r = ENT_REF(en), n = a + r;
+        const double2 p = ab[l];
+        if (!(p.x >= 0.0) || n == 0) continue;  // masked locus: no PMFData (main.rs:556); 0/0 entry: exactly zero (Q14)
+        s += dm_log_bb_pmf(lf, p.x, p.y, a, r);
+        if (EXPECTED) {
+            if (n >= 5 && n <= 8) e += etab[(uint64_t)l * 4 + (n - 5)];
+            else if (n >= 4 && n <= (uint32_t)OV_NE) e += otab[(uint64_t)l * OV_ROW + OV_EOFF + (n - 4)];
+        }
     }
     o_ll[row] = s;
     if (EXPECTED) o_ell[row] = e;
+}
+
+// rows that have an overflow entry with alt+ref > OV_NE (static; arbitrary order, every row at most once)
+__global__ __launch_bounds__(256) void k_ovf_slow_rows(uint64_t n_rows, const uint64_t *__restrict__ ovf_ptr,
+                                                       const uint64_t *__restrict__ ovf_ent, uint32_t *__restrict__ rows,
+                                                       uint32_t *__restrict__ n_out)
+{
+    const uint64_t row = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= n_rows) return;
+    bool slow = false;
+    for (uint64_t i = ovf_ptr[row], end = ovf_ptr[row + 1]; i < end; i++) {
+        const uint64_t en = ovf_ent[i];
+        slow |= ENT_ALT(en) + ENT_REF(en) > (uint32_t)OV_NE;
+    }
+    if (slow) rows[atomicAdd(n_out, 1u)] = (uint32_t)row;
+}
+// their expected terms (stats.rs:8-22 in the reference's log-space form), added to the row's sum
+__global__ __launch_bounds__(256) void k_ovf_cell_slow_e(uint32_t n_slow, const uint32_t *__restrict__ rows,
+                                                         const uint64_t *__restrict__ ovf_ptr,
+                                                         const uint64_t *__restrict__ ovf_ent, const double2 *__restrict__ ab,
+                                                         const double *__restrict__ lf, double *__restrict__ o_ell)
+{
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_slow) return;
+    const uint32_t row = rows[k];
+    double e = 0.0;
+    for (uint64_t i = ovf_ptr[row], end = ovf_ptr[row + 1]; i < end; i++) {
+        const uint64_t en = ovf_ent[i];
+        const uint32_t n = ENT_ALT(en) + ENT_REF(en);
+        if (n <= (uint32_t)OV_NE) continue;
+        const double2 p = ab[ENT_IDX(en)];
+        if (p.x >= 0.0) e += dm_expected_log_pmf(lf, p.x, p.y, n);
+    }
+    o_ell[row] += e;
 }
 
 // chunk-group partials in group order, then the row's overflow sum, then the normalisation (main.rs:314-323)
@@ -1230,8 +1242,8 @@ void tiled_free(cellector_ctx *c)
     dev_free(c->tile_ptr); dev_free(c->tiles); dev_free(c->thdr); dev_free(c->ovf_ptr); dev_free(c->ovf_ent);
     dev_free(c->c4_ptr); dev_free(c->c4_ent); dev_free(c->ovc_ptr); dev_free(c->ovc_ent);
     dev_free(c->hist_all); dev_free(c->tab); dev_free(c->part); dev_free(c->ab3);
-    dev_free(c->masked_cnt); dev_free(c->flag_bits); dev_free(c->ovf_perm); dev_free(c->ovf_val); dev_free(c->ovf_tab);
-    dev_free(c->ovf_sum); dev_free(c->ovf_lp); dev_free(c->ovc_locus); dev_free(c->ovf_nmask); dev_free(c->tile_work); dev_free(c->minlist); dev_free(c->hist_min); dev_free(c->roff); dev_free(c->c4r); dev_free(c->mroff); dev_free(c->mbeg);
+    dev_free(c->masked_cnt); dev_free(c->flag_bits); dev_free(c->ovf_tab); dev_free(c->ovf_etab);
+    dev_free(c->ovf_sum); dev_free(c->ovf_lp); dev_free(c->ovc_locus); dev_free(c->ovf_slow_rows); dev_free(c->ovf_nmask); dev_free(c->tile_work); dev_free(c->minlist); dev_free(c->hist_min); dev_free(c->roff); dev_free(c->c4r); dev_free(c->mroff); dev_free(c->mbeg);
     c->mroff_cap = 0;
     c->tiled_ready = false;
     c->ovf_n = 0; c->n_masked_loci = 0;
@@ -1336,20 +1348,26 @@ cellector_status tiled_build(cellector_ctx *c)
 
     // ---- overflow values: by-locus storage + permutation for the by-cell gather
     if (c->ovf_n >= (1ull << 32)) return ctx_fail(c, CELLECTOR_EINVAL, "tiled engine: more than 2^32 overflow entries per shard");
-    CHK(dev_alloc(c, &c->ovf_perm, c->ovf_n));
-    CHK(dev_alloc(c, &c->ovf_val, 3 * c->ovf_n));
     CHK(dev_alloc(c, &c->ovf_sum, 3 * 2 * nloc));
     CHK(dev_alloc(c, &c->ovf_lp, c->ovf_n));
     CHK(dev_alloc(c, &c->ovf_tab, L * OV_ROW));
+    CHK(dev_alloc(c, &c->ovf_etab, L * 4));
     CHK(dev_alloc(c, &c->ovf_nmask, L));
     CHK(dev_alloc(c, &c->ovc_locus, c->ovf_n));
+    CHK(dev_alloc(c, &c->ovf_slow_rows, nloc + 1));
+    c->ovf_n_slow = 0;
+    if (nloc && c->ovf_n) {
+        uint32_t *cnt = c->ovf_slow_rows + nloc;  // the list's counter lives behind it
+        HIPCHK(c, hipMemsetAsync(cnt, 0, sizeof(uint32_t), c->stream));
+        hipLaunchKernelGGL(k_ovf_slow_rows, dim3(gcap(nloc, 256, 0x7fffffffu)), dim3(256), 0, c->stream, nloc, c->ovf_ptr, c->ovf_ent,
+                           c->ovf_slow_rows, cnt);
+        HIPCHK(c, hipMemcpyAsync(&c->ovf_n_slow, cnt, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
     if (L && c->ovf_n)
         hipLaunchKernelGGL(k_ovf_locus_ids, dim3(gcap(L, 4)), dim3(256), 0, c->stream, L, c->ovc_ptr, c->ovc_locus);
-    if (L && c->ovf_n) {
-        hipLaunchKernelGGL(k_ovf_perm, dim3(gcap(L, 4)), dim3(256), 0, c->stream, L, c->ovc_ptr, c->ovc_ent, c->ovf_ptr,
-                           c->ovf_ent, c->ovf_perm);
+    if (L && c->ovf_n)
         hipLaunchKernelGGL(k_ovf_nmask, dim3(gcap(L, 4)), dim3(256), 0, c->stream, L, c->ovc_ptr, c->ovc_ent, c->ovf_nmask);
-    }
     HIPCHK(c, hipGetLastError());
 
     // ---- per-iteration workspaces
@@ -1394,33 +1412,29 @@ cellector_status tiled_build(cellector_ctx *c)
 
 // Overflow side of one pass: tables -> per-entry values (locus-major) -> per-cell sums.  Launched on the side stream so
 // that these small, latency-bound kernels run next to the tile kernel instead of in front of it.
-// Overflow side of one pass: per-locus tables -> per-entry values (by-locus order) on stream `st`, then the per-cell
-// gather of those values on stream `sg` (which may run beside the tile kernel: it is memory latency, hardly any ALU).
-static void launch_overflow_values(cellector_ctx *c, hipStream_t st, const double2 *ab, int set, bool expected)
+// cell side of the overflow entries of one pass, on stream `st`
+static void launch_overflow_cell(cellector_ctx *c, hipStream_t st, const double2 *ab, int set, bool expected)
 {
-    double2 *val = c->ovf_val + (uint64_t)set * c->ovf_n;
-    double *lp_only = set == 0 ? c->ovf_lp : (double *)nullptr;
-    const unsigned tg = gcap(c->L * 3, 256, 0x7fffffffu), eg = gcap(c->L * 16, 256, 0x7fffffffu),
-                   vg = gcap(c->ovf_n, 256, 0x7fffffffu);
-    hipLaunchKernelGGL(k_ovf_tables, dim3(tg), dim3(256), 0, st, c->L, ab, c->ovf_tab);
+    double *o_ll = c->ovf_sum + (uint64_t)set * 2 * c->nloc, *o_ell = o_ll + c->nloc;
+    const unsigned g = gcap(c->nloc, 256, 0x7fffffffu), eg = gcap(c->L * 16, 256, 0x7fffffffu);
     if (expected) {
-        hipLaunchKernelGGL(k_ovf_tables_e, dim3(eg), dim3(256), 0, st, c->L, ab, c->ovf_nmask, c->ovf_tab);
-        hipLaunchKernelGGL(k_ovf_values<true>, dim3(vg), dim3(256), 0, st, c->ovf_n, c->ovc_locus, c->ovc_ent, ab, c->lf, c->ovf_tab,
-                           val, lp_only);
+        hipLaunchKernelGGL(k_ovf_tables_e, dim3(eg), dim3(256), 0, st, c->L, ab, c->ovf_nmask, c->ovf_tab, c->ovf_etab);
+        hipLaunchKernelGGL(k_ovf_cell_direct<true>, dim3(g), dim3(256), 0, st, c->nloc, c->ovf_ptr, c->ovf_ent, ab, c->lf,
+                           c->ovf_etab, c->ovf_tab, o_ll, o_ell);
+        if (c->ovf_n_slow)
+            hipLaunchKernelGGL(k_ovf_cell_slow_e, dim3(gcap(c->ovf_n_slow, 256)), dim3(256), 0, st, c->ovf_n_slow, c->ovf_slow_rows,
+                               c->ovf_ptr, c->ovf_ent, ab, c->lf, o_ell);
     } else {
-        hipLaunchKernelGGL(k_ovf_values<false>, dim3(vg), dim3(256), 0, st, c->ovf_n, c->ovc_locus, c->ovc_ent, ab, c->lf, c->ovf_tab,
-                           val, lp_only);
+        hipLaunchKernelGGL(k_ovf_cell_direct<false>, dim3(g), dim3(256), 0, st, c->nloc, c->ovf_ptr, c->ovf_ent, ab, c->lf,
+                           c->ovf_etab, c->ovf_tab, o_ll, o_ell);
     }
 }
-static void launch_overflow_gather(cellector_ctx *c, hipStream_t sg, int set, bool expected)
+// locus side: the overflow entries' log-pmfs in by-locus order (ovf_lp), on stream `st`
+static void launch_overflow_locus_values(cellector_ctx *c, hipStream_t st, const double2 *ab)
 {
-    const double2 *val = c->ovf_val + (uint64_t)set * c->ovf_n;
-    double *o_ll = c->ovf_sum + (uint64_t)set * 2 * c->nloc, *o_ell = o_ll + c->nloc;
-    const unsigned g = gcap(c->nloc, 256, 0x7fffffffu);
-    if (expected)
-        hipLaunchKernelGGL(k_ovf_cell_sums<true>, dim3(g), dim3(256), 0, sg, c->nloc, c->ovf_ptr, c->ovf_perm, val, o_ll, o_ell);
-    else
-        hipLaunchKernelGGL(k_ovf_cell_sums<false>, dim3(g), dim3(256), 0, sg, c->nloc, c->ovf_ptr, c->ovf_perm, val, o_ll, o_ell);
+    hipLaunchKernelGGL(k_ovf_tables, dim3(gcap(c->L * 3, 256, 0x7fffffffu)), dim3(256), 0, st, c->L, ab, c->ovf_tab);
+    hipLaunchKernelGGL(k_ovf_values, dim3(gcap(c->ovf_n, 256, 0x7fffffffu)), dim3(256), 0, st, c->ovf_n, c->ovc_locus, c->ovc_ent, ab,
+                       c->lf, c->ovf_tab, c->ovf_lp);
 }
 
 static bool have_overflow(const cellector_ctx *c) { return c->ovf_n != 0 && c->L != 0 && c->nloc != 0; }
@@ -1495,25 +1509,32 @@ static cellector_status run_tile_pass(cellector_ctx *c, int set, bool expected)
     return CELLECTOR_OK;
 }
 
-cellector_status tiled_cell_pass(cellector_ctx *c, const double2 *ab, double *norm_out)
+cellector_status tiled_cell_pass(cellector_ctx *c, const double2 *ab, double *norm_out, bool for_em)
 {
     if (c->nloc == 0) return CELLECTOR_OK;
     timer_begin(c, CELLECTOR_K_CELL_LL);
     const bool ovf = have_overflow(c);
-    // The overflow chain (tables -> values -> per-cell gather) runs on the side stream beside the tile kernel (overlap 2):
-    // the tile kernel's persistent workgroups leave few wave slots, so the chain is several times slower there than
-    // alone (1.6 against 0.7 ms at cfg4), but it ends well inside the tile kernel's 2.5 ms and costs that kernel 0.27 ms,
-    // less than running any part of it in front (overlap 1: only the gather beside it; 0: nothing).
-    if (ovf && c->overlap != 2) launch_overflow_values(c, c->stream, ab, 0, c->compute_expected);
+    // The overflow entries' cell side runs on the side stream BESIDE the tile kernel: in the few wave slots the persistent
+    // tile workgroups leave it is several times slower than alone, but it ends well inside the tile kernel's time.  In an
+    // EM iteration the locus side's values follow it there; the locus finalize waits for them (tiled_locus_pass).
+    // (overlap 0: everything in the main stream.)
     CHK(build_tile_tables(c, ab, 0, c->compute_expected));
     if (ovf && c->overlap) {
         CHK(side_fork(c));
-        if (c->overlap == 2) launch_overflow_values(c, c->side, ab, 0, c->compute_expected);
-        launch_overflow_gather(c, c->side, 0, c->compute_expected);
+        launch_overflow_cell(c, c->side, ab, 0, c->compute_expected);
+        HIPCHK(c, hipEventRecord(c->ev_join, c->side));
+        if (for_em) {
+            launch_overflow_locus_values(c, c->side, ab);
+            HIPCHK(c, hipEventRecord(c->ev_join2, c->side));
+            c->ovf_locus_pending = true;
+        }
         CHK(run_tile_pass(c, 0, c->compute_expected));
-        CHK(side_join(c));
+        HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
     } else {
-        if (ovf) launch_overflow_gather(c, c->stream, 0, c->compute_expected);
+        if (ovf) {
+            launch_overflow_cell(c, c->stream, ab, 0, c->compute_expected);
+            if (for_em) launch_overflow_locus_values(c, c->stream, ab);
+        }
         CHK(run_tile_pass(c, 0, c->compute_expected));
     }
     double *part_ll = c->part, *part_ell = c->part + (uint64_t)c->t_groups * c->t_npad;
@@ -1586,6 +1607,10 @@ cellector_status tiled_locus_pass(cellector_ctx *c)
         hipLaunchKernelGGL(k_minority_ranges, dim3(R * c->lr_sub), dim3(LR_THREADS), 0, c->stream, c->locus_mode, c->nloc, c->L, R,
                            c->lr_sub, c->mroff_cap, c->d_counters + DC_N_MIN, c->mroff, c->mbeg, c->c4r, c->hist_min);
     }
+    if (c->ovf_locus_pending) {  // the overflow entries' log-pmfs of this iteration (side stream)
+        HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join2, 0));
+        c->ovf_locus_pending = false;
+    }
     hipLaunchKernelGGL(k_locus_finalize, dim3(gcap(c->L * LF_LANES, 256, 0x7fffffffu)), dim3(256), 0, c->stream, c->L, c->locus_mode,
                        c->nloc, c->lr_sub, c->d_counters + DC_N_MIN, c->hist_min, c->flag_bits, c->hist_all, c->tab_em,
                        (uint32_t)c->tab_em_stride, c->mask, c->ovf_n ? c->ovc_ptr : (const uint64_t *)nullptr, c->ovc_ent,
@@ -1619,20 +1644,15 @@ cellector_status tiled_posteriors(cellector_ctx *c, double mf0, double lp_min, d
     if (c->nloc == 0) return CELLECTOR_OK;
     timer_begin(c, CELLECTOR_K_POSTERIOR);
     const bool ovf = have_overflow(c);
-    if (ovf && c->overlap != 2)
-        for (int set = 0; set < 3; set++) launch_overflow_values(c, c->stream, c->ab3 + (uint64_t)set * L, set, false);
     for (int set = 0; set < 3; set++) CHK(build_tile_tables(c, c->ab3 + (uint64_t)set * L, set, false));
     if (ovf && c->overlap) {
         CHK(side_fork(c));
-        for (int set = 0; set < 3; set++) {
-            if (c->overlap == 2) launch_overflow_values(c, c->side, c->ab3 + (uint64_t)set * L, set, false);
-            launch_overflow_gather(c, c->side, set, false);
-        }
+        for (int set = 0; set < 3; set++) launch_overflow_cell(c, c->side, c->ab3 + (uint64_t)set * L, set, false);
         for (int set = 0; set < 3; set++) CHK(run_tile_pass(c, set, false));
         CHK(side_join(c));
     } else {
         if (ovf)
-            for (int set = 0; set < 3; set++) launch_overflow_gather(c, c->stream, set, false);
+            for (int set = 0; set < 3; set++) launch_overflow_cell(c, c->stream, c->ab3 + (uint64_t)set * L, set, false);
         for (int set = 0; set < 3; set++) CHK(run_tile_pass(c, set, false));
     }
     hipLaunchKernelGGL(k_posterior_finalize, dim3(gcap(c->nloc, 256, 0x7fffffffu)), dim3(256), 0, c->stream, c->nloc,

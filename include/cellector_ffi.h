@@ -59,8 +59,8 @@ cellector_status cellector_set_stream(cellector_ctx *ctx, void *hip_stream);
  * "locus_mode" (engine 2, default 0: per iteration the device picks how the per-locus minority counts
  * of get_locus_log_likelihoods, main.rs:368-420, are formed — 2 = walk only the excluded cells' rows,
  * 1 = stream the whole compact CSC past the exclusion bitmask; bit-identical results),
- * "overlap" (engine 2, default 2: the kernels of the few entries with alt+ref = 0 or > 4 run on a side
- * stream beside the table-lookup kernel; 1 = only their per-cell gather; 0 = everything in one stream). */
+ * "overlap" (engine 2, default 1: the kernels of the few entries with alt+ref = 0 or > 4 run on a side
+ * stream beside the table-lookup kernel; 0 = everything in one stream). */
 cellector_status cellector_set_option(cellector_ctx *ctx, const char *key, int64_t value);
 
 /* ---- sharding (before ingest) --------------------------------------------------------------- */
