@@ -109,6 +109,7 @@ struct cellector_ctx {
     bool ovf_locus_pending = false;  // the side stream still owes this iteration's ovf_lp (event ev_join2)
     double *ovf_lp = nullptr;        // [ovf_n] the EM pass' overflow log-pmfs alone, by-locus order (locus pass)
     double *ovf_sum = nullptr;       // [3][2][nloc] per-cell sums of the overflow values (ll, expected) per table set
+    uint64_t *ovf_ell_ptr = nullptr, *ovf_ell = nullptr;  // 64-row ELLPACK copy of the overflow CSR (cell side): [groups+1], slots
     uint32_t *ovf_slow_rows = nullptr;  // [ovf_n_slow] rows with an overflow entry whose alt+ref exceeds the E tables
     uint32_t ovf_n_slow = 0;
     uint32_t *ovc_locus = nullptr;   // [ovf_n] compact locus index of every overflow entry, by-locus order

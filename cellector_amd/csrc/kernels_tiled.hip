@@ -467,32 +467,64 @@ __global__ __launch_bounds__(256) void k_ovf_nmask(uint64_t L, const uint64_t *_
 // 0.26 GB of values) and slowed the tile kernel beside it more.  k_cell_finalize adds the result to the tile partials.
 // (48 VGPRs and no calls: the persistent tile workgroups leave 96 VGPRs per SIMD, so two waves of this kernel fit beside
 // them on every SIMD; the entry loop is not unrolled — a row has ~16 overflow entries and hundreds of thousands of rows
-// are in flight.  The one rare case that needs the long log-space fold — the expected term of a total above OV_NE — is
-// left to k_ovf_cell_slow_e, which visits only the rows that have such an entry.)
+// are in flight.  Entries with a total above OV_NE (rare; they need the generic paths: Lanczos ln_gamma beyond the factorial
+// table, the log-space fold of the expected term) are left to k_ovf_cell_slow, which visits only the rows that have one.)
+// The rows' entries come from a 64-row ELLPACK copy (ovf_ell: entry k of the 64 rows of a group side by side, padded with
+// all-ones to the group's longest row): a wave's loads are coalesced and every line is used once.  Reading the CSR row by
+// row, a lane per row, re-fetched each row's 128-byte line for every one of its entries (measured 2.1 GB for 0.13 GB).
+#define OVF_PAD (~0ull)
 template <bool EXPECTED>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(48))) void k_ovf_cell_direct(
-    uint64_t n_rows, const uint64_t *__restrict__ ovf_ptr, const uint64_t *__restrict__ ovf_ent,
+    uint64_t n_rows, const uint64_t *__restrict__ ell_ptr, const uint64_t *__restrict__ ell,
     const double2 *__restrict__ ab, const double *__restrict__ lf, const double *__restrict__ etab,
     const double *__restrict__ otab, double *__restrict__ o_ll, double *__restrict__ o_ell)
 {
     const uint64_t row = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (row >= n_rows) return;
+    if (row >= n_rows) return;  // (rows beyond the end have no lane; their slots are padding)
     double s = 0.0, e = 0.0;
-    const uint64_t end = ovf_ptr[row + 1];
+    const uint64_t grp = row >> 6, base = ell_ptr[grp] + (row & 63), end = ell_ptr[grp + 1];
 #pragma unroll 1
-    for (uint64_t i = ovf_ptr[row]; i < end; i++) {
-        const uint64_t en = ovf_ent[i];
+    for (uint64_t i = base; i < end; i += 64) {
+        const uint64_t en = ell[i];
+        if (en == OVF_PAD) continue;
         const uint32_t l = ENT_IDX(en), a = ENT_ALT(en), r = ENT_REF(en), n = a + r;
         const double2 p = ab[l];
-        if (!(p.x >= 0.0) || n == 0) continue;  // masked locus: no PMFData (main.rs:556); 0/0 entry: exactly zero (Q14)
-        s += dm_log_bb_pmf(lf, p.x, p.y, a, r);
+        // masked locus: no PMFData (main.rs:556); 0/0 entry: exactly zero (Q14); a total above OV_NE: k_ovf_cell_slow
+        if (!(p.x >= 0.0) || n == 0 || n > (uint32_t)OV_NE) continue;
+        // = dm_log_bb_pmf for these totals: ln C out of the factorial table, one log per chunk of 8 factors
+        s += (lf[n] - lf[a] - lf[r]) + dm_log_beta_ratio(p.x, p.y, a, r);
         if (EXPECTED) {
             if (n >= 5 && n <= 8) e += etab[(uint64_t)l * 4 + (n - 5)];
-            else if (n >= 4 && n <= (uint32_t)OV_NE) e += otab[(uint64_t)l * OV_ROW + OV_EOFF + (n - 4)];
+            else e += otab[(uint64_t)l * OV_ROW + OV_EOFF + (n - 4)];
         }
     }
     o_ll[row] = s;
     if (EXPECTED) o_ell[row] = e;
+}
+
+// 64-row ELLPACK copy of the overflow CSR.  COUNT: slots of group g = 64 x its longest row; FILL: lane = row & 63 writes
+// its entries at ell_ptr[g] + k * 64 + lane and pads.  One wave per group.
+template <bool FILL>
+__global__ __launch_bounds__(256) void k_ovf_ell_build(uint64_t n_rows, const uint64_t *__restrict__ ovf_ptr,
+                                                       const uint64_t *__restrict__ ovf_ent, uint64_t *__restrict__ ell_ptr,
+                                                       uint64_t *__restrict__ ell)
+{
+    const int lane = threadIdx.x & 63;
+    const uint64_t grp = ((uint64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
+    const uint64_t n_grp = (n_rows + 63) >> 6;
+    if (grp >= n_grp) return;
+    const uint64_t row = grp * 64 + lane;
+    uint64_t beg = 0, len = 0;
+    if (row < n_rows) { beg = ovf_ptr[row]; len = ovf_ptr[row + 1] - beg; }
+    uint64_t kmax = len;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) kmax = max(kmax, (uint64_t)__shfl_xor((long long)kmax, off, 64));
+    if (!FILL) {
+        if (lane == 0) ell_ptr[grp] = kmax * 64;
+        return;
+    }
+    const uint64_t base = ell_ptr[grp] + lane;
+    for (uint64_t k = 0; k < kmax; k++) ell[base + k * 64] = k < len ? ovf_ent[beg + k] : OVF_PAD;
 }
 
 // rows that have an overflow entry with alt+ref > OV_NE (static; arbitrary order, every row at most once)
@@ -509,24 +541,29 @@ __global__ __launch_bounds__(256) void k_ovf_slow_rows(uint64_t n_rows, const ui
     }
     if (slow) rows[atomicAdd(n_out, 1u)] = (uint32_t)row;
 }
-// their expected terms (stats.rs:8-22 in the reference's log-space form), added to the row's sum
-__global__ __launch_bounds__(256) void k_ovf_cell_slow_e(uint32_t n_slow, const uint32_t *__restrict__ rows,
-                                                         const uint64_t *__restrict__ ovf_ptr,
-                                                         const uint64_t *__restrict__ ovf_ent, const double2 *__restrict__ ab,
-                                                         const double *__restrict__ lf, double *__restrict__ o_ell)
+// their log-pmfs and expected terms (stats.rs:8-22 in the reference's log-space form), added to the row's sums
+template <bool EXPECTED>
+__global__ __launch_bounds__(256) void k_ovf_cell_slow(uint32_t n_slow, const uint32_t *__restrict__ rows,
+                                                       const uint64_t *__restrict__ ovf_ptr,
+                                                       const uint64_t *__restrict__ ovf_ent, const double2 *__restrict__ ab,
+                                                       const double *__restrict__ lf, double *__restrict__ o_ll,
+                                                       double *__restrict__ o_ell)
 {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n_slow) return;
     const uint32_t row = rows[k];
-    double e = 0.0;
+    double s = 0.0, e = 0.0;
     for (uint64_t i = ovf_ptr[row], end = ovf_ptr[row + 1]; i < end; i++) {
         const uint64_t en = ovf_ent[i];
-        const uint32_t n = ENT_ALT(en) + ENT_REF(en);
+        const uint32_t a = ENT_ALT(en), r = ENT_REF(en), n = a + r;
         if (n <= (uint32_t)OV_NE) continue;
         const double2 p = ab[ENT_IDX(en)];
-        if (p.x >= 0.0) e += dm_expected_log_pmf(lf, p.x, p.y, n);
+        if (!(p.x >= 0.0)) continue;
+        s += dm_log_bb_pmf(lf, p.x, p.y, a, r);
+        if (EXPECTED) e += dm_expected_log_pmf(lf, p.x, p.y, n);
     }
-    o_ell[row] += e;
+    o_ll[row] += s;
+    if (EXPECTED) o_ell[row] += e;
 }
 
 // chunk-group partials in group order, then the row's overflow sum, then the normalisation (main.rs:314-323)
@@ -1243,7 +1280,7 @@ void tiled_free(cellector_ctx *c)
     dev_free(c->c4_ptr); dev_free(c->c4_ent); dev_free(c->ovc_ptr); dev_free(c->ovc_ent);
     dev_free(c->hist_all); dev_free(c->tab); dev_free(c->part); dev_free(c->ab3);
     dev_free(c->masked_cnt); dev_free(c->flag_bits); dev_free(c->ovf_tab); dev_free(c->ovf_etab);
-    dev_free(c->ovf_sum); dev_free(c->ovf_lp); dev_free(c->ovc_locus); dev_free(c->ovf_slow_rows); dev_free(c->ovf_nmask); dev_free(c->tile_work); dev_free(c->minlist); dev_free(c->hist_min); dev_free(c->roff); dev_free(c->c4r); dev_free(c->mroff); dev_free(c->mbeg);
+    dev_free(c->ovf_sum); dev_free(c->ovf_lp); dev_free(c->ovc_locus); dev_free(c->ovf_slow_rows); dev_free(c->ovf_ell_ptr); dev_free(c->ovf_ell); dev_free(c->ovf_nmask); dev_free(c->tile_work); dev_free(c->minlist); dev_free(c->hist_min); dev_free(c->roff); dev_free(c->c4r); dev_free(c->mroff); dev_free(c->mbeg);
     c->mroff_cap = 0;
     c->tiled_ready = false;
     c->ovf_n = 0; c->n_masked_loci = 0;
@@ -1354,6 +1391,21 @@ cellector_status tiled_build(cellector_ctx *c)
     CHK(dev_alloc(c, &c->ovf_etab, L * 4));
     CHK(dev_alloc(c, &c->ovf_nmask, L));
     CHK(dev_alloc(c, &c->ovc_locus, c->ovf_n));
+    {
+        const uint64_t n_grp = (nloc + 63) / 64;
+        uint64_t slots = 0;
+        CHK(dev_alloc(c, &c->ovf_ell_ptr, n_grp + 1));
+        HIPCHK(c, hipMemsetAsync(c->ovf_ell_ptr + n_grp, 0, 8, c->stream));
+        if (nloc)
+            hipLaunchKernelGGL(k_ovf_ell_build<false>, dim3(gcap(n_grp * 64, 256, 0x7fffffffu)), dim3(256), 0, c->stream, nloc,
+                               c->ovf_ptr, c->ovf_ent, c->ovf_ell_ptr, (uint64_t *)nullptr);
+        CHK(dev_exclusive_scan_u64(c, c->ovf_ell_ptr, n_grp + 1, &slots));
+        CHK(dev_alloc(c, &c->ovf_ell, slots));
+        if (nloc)
+            hipLaunchKernelGGL(k_ovf_ell_build<true>, dim3(gcap(n_grp * 64, 256, 0x7fffffffu)), dim3(256), 0, c->stream, nloc,
+                               c->ovf_ptr, c->ovf_ent, c->ovf_ell_ptr, c->ovf_ell);
+        HIPCHK(c, hipGetLastError());
+    }
     CHK(dev_alloc(c, &c->ovf_slow_rows, nloc + 1));
     c->ovf_n_slow = 0;
     if (nloc && c->ovf_n) {
@@ -1419,14 +1471,17 @@ static void launch_overflow_cell(cellector_ctx *c, hipStream_t st, const double2
     const unsigned g = gcap(c->nloc, 256, 0x7fffffffu), eg = gcap(c->L * 16, 256, 0x7fffffffu);
     if (expected) {
         hipLaunchKernelGGL(k_ovf_tables_e, dim3(eg), dim3(256), 0, st, c->L, ab, c->ovf_nmask, c->ovf_tab, c->ovf_etab);
-        hipLaunchKernelGGL(k_ovf_cell_direct<true>, dim3(g), dim3(256), 0, st, c->nloc, c->ovf_ptr, c->ovf_ent, ab, c->lf,
+        hipLaunchKernelGGL(k_ovf_cell_direct<true>, dim3(g), dim3(256), 0, st, c->nloc, c->ovf_ell_ptr, c->ovf_ell, ab, c->lf,
                            c->ovf_etab, c->ovf_tab, o_ll, o_ell);
         if (c->ovf_n_slow)
-            hipLaunchKernelGGL(k_ovf_cell_slow_e, dim3(gcap(c->ovf_n_slow, 256)), dim3(256), 0, st, c->ovf_n_slow, c->ovf_slow_rows,
-                               c->ovf_ptr, c->ovf_ent, ab, c->lf, o_ell);
+            hipLaunchKernelGGL(k_ovf_cell_slow<true>, dim3(gcap(c->ovf_n_slow, 256)), dim3(256), 0, st, c->ovf_n_slow, c->ovf_slow_rows,
+                               c->ovf_ptr, c->ovf_ent, ab, c->lf, o_ll, o_ell);
     } else {
-        hipLaunchKernelGGL(k_ovf_cell_direct<false>, dim3(g), dim3(256), 0, st, c->nloc, c->ovf_ptr, c->ovf_ent, ab, c->lf,
+        hipLaunchKernelGGL(k_ovf_cell_direct<false>, dim3(g), dim3(256), 0, st, c->nloc, c->ovf_ell_ptr, c->ovf_ell, ab, c->lf,
                            c->ovf_etab, c->ovf_tab, o_ll, o_ell);
+        if (c->ovf_n_slow)
+            hipLaunchKernelGGL(k_ovf_cell_slow<false>, dim3(gcap(c->ovf_n_slow, 256)), dim3(256), 0, st, c->ovf_n_slow, c->ovf_slow_rows,
+                               c->ovf_ptr, c->ovf_ent, ab, c->lf, o_ll, o_ell);
     }
 }
 // locus side: the overflow entries' log-pmfs in by-locus order (ovf_lp), on stream `st`
