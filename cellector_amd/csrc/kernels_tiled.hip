@@ -335,10 +335,6 @@ __device__ __noinline__ double ov_slow_log_pmf(const double *lf, double alpha, d
 {
     return dm_log_bb_pmf(lf, alpha, beta, a, r);
 }
-__device__ __noinline__ double ov_slow_expected(const double *lf, double alpha, double beta, uint32_t n)
-{
-    return dm_expected_log_pmf(lf, alpha, beta, n);
-}
 
 // ln sum_k pmf(k)^2 (stats.rs:8-22) for 4 <= n <= OV_NE by the pmf ratio recurrence of dm_expected_log_pmf, with pmf(0) built
 // from per-factor ratios (each in (0, 1]: no overflow of long products at these n)
@@ -646,8 +642,6 @@ __device__ __forceinline__ bool locus_by_minority(int mode, uint32_t n_min, uint
 
 struct __attribute__((packed, aligned(4))) ls_u3 { uint32_t x, y, z; };  // 12-byte load at a 4-byte aligned address
 #define LS_THREADS 1024
-#define LS_NPK ((T_NCODE + 4) / 5)
-#define LS_FLUSH 15  // vector iterations between wave reductions: 15*4 = 60 per lane and field, 64*60 < 4096 (12-bit fields)
 template <bool BITS_IN_LDS, int EB>
 __global__ __launch_bounds__(LS_THREADS) void k_locus_stats2(uint64_t L, uint32_t nbits_words,
                                                              const uint64_t *__restrict__ c4_ptr,
