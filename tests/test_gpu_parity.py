@@ -179,6 +179,46 @@ def test_locus_pass_forms_are_bit_identical(mods):
             assert np.array_equal(a[k], c[k]), k
 
 
+def test_overflow_side_stream_equals_in_stream(mods):
+    """Engine 2 runs the kernels of the entries with alt+ref = 0 or > 4 on a side stream beside the table-lookup kernel
+    (option overlap, default 1) — same kernels, same arithmetic as in one stream: every output must agree to the bit.
+    Counts are drawn wide here so that a good part of the entries takes that path, some of them the rare-total kernel."""
+    if mods["engine"] != 2:
+        pytest.skip("engine 2 option")
+    rng = np.random.default_rng(11)
+    L, N = 700, 1300
+    lo, ce, al, re = mods["synth"].generate_coo(L, N, 0.1, seed=8, minority_fraction=0.1)
+    big = rng.random(len(al)) < 0.2
+    al = np.where(big, al * rng.integers(1, 12, len(al)), al).astype(np.uint32)
+    re = np.where(big, re * rng.integers(1, 12, len(re)), re).astype(np.uint32)
+    outs = []
+    for ov in (1, 0):
+        g = mods["Cellector"](0)
+        g.set_option("overlap", ov)
+        g.load_coo(L, N, lo, ce, al, re)
+        o = mods["ob"].Oracle.from_coo(L, N, lo, ce, al, re)
+        run = []
+        for _ in range(30):
+            sg, so = g.em_iteration(5.0), o.em_iteration(5.0)
+            _check_iteration(g, o, sg, so)
+            run.append((g.cell_outputs(), g.locus_outputs()))
+            if not sg.any_change:
+                break
+        pg, _ = _check_posteriors(mods, g, o)
+        outs.append((run, pg))
+        g.close()
+        o.close()
+    (run_a, post_a), (run_b, post_b) = outs
+    assert len(run_a) == len(run_b)
+    for (ca, la), (cb, lb) in zip(run_a, run_b):
+        for k in ca:
+            assert np.array_equal(ca[k], cb[k]), k
+        for k in la:
+            assert np.array_equal(la[k], lb[k]), k
+    for k in post_a:
+        assert np.array_equal(post_a[k], post_b[k]), k
+
+
 def test_ll_pass_under_caller_alpha_beta_and_mask(mods):
     g, o, _ = _case(mods, 1500, 800, 0.1, seed=3)
     rng = np.random.default_rng(0)
