@@ -162,7 +162,11 @@ cellector_status cellector_set_option(cellector_ctx *c, const char *key, int64_t
     if (!strcmp(key, "compute_expected")) c->compute_expected = v != 0;
     else if (!strcmp(key, "timing")) c->timing = v != 0;
     else if (!strcmp(key, "keep_coo")) c->keep_coo = v != 0;
-    else if (!strcmp(key, "overlap")) c->overlap = v != 0;
+    else if (!strcmp(key, "overlap")) {
+        if (v < 0 || v > 2) return ctx_fail(c, CELLECTOR_EINVAL, "overlap must be 0, 1 or 2");
+        c->overlap = (int)v;
+    }
+    else if (!strcmp(key, "side_lds")) c->side_lds = (int)v;
     else if (!strcmp(key, "locus_mode")) {
         if (v < 0 || v > 2) return ctx_fail(c, CELLECTOR_EINVAL, "locus_mode must be 0 (automatic), 1 (stream) or 2 (minority-driven)");
         c->locus_mode = (int)v;

@@ -106,12 +106,14 @@ struct cellector_ctx {
     uint64_t ovf_n = 0;
     double *ovf_tab = nullptr;       // [L][128] per-locus cumulative-log / expected tables for overflow entries
     double *ovf_etab = nullptr;      // [L][4] E(n), n = 5..8: compact copy for the cell side
+    int side_lds = 0;                // option "side_lds": dynamic LDS bytes requested by the cell-side overflow kernel (residency throttle)
     bool ovf_locus_pending = false;  // the side stream still owes this iteration's ovf_lp (event ev_join2)
     double *ovf_lp = nullptr;        // [ovf_n] the EM pass' overflow log-pmfs alone, by-locus order (locus pass)
     double *ovf_sum = nullptr;       // [3][2][nloc] per-cell sums of the overflow values (ll, expected) per table set
     uint64_t *ovf_ell_ptr = nullptr, *ovf_ell = nullptr;  // 64-row ELLPACK copy of the overflow CSR (cell side): [groups+1], slots
-    uint32_t *ovf_slow_rows = nullptr;  // [ovf_n_slow] rows with an overflow entry whose alt+ref exceeds the E tables
-    uint32_t ovf_n_slow = 0;
+    uint32_t *ovf_tier_row[2] = {nullptr, nullptr};  // the overflow entries with alt+ref in 9..17 (tier 0) / above (tier 1):
+    uint64_t *ovf_tier_ent[2] = {nullptr, nullptr};  //   their rows and packed entries, in row order
+    uint64_t ovf_n_tier[2] = {0, 0};
     uint32_t *ovc_locus = nullptr;   // [ovf_n] compact locus index of every overflow entry, by-locus order
     uint32_t *ovf_nmask = nullptr;   // [L] which alt+ref totals (4..17) occur among the locus' overflow entries
     uint64_t *c4_ptr = nullptr;      // [L+1] compact CSC of regular entries

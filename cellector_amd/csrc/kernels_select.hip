@@ -177,7 +177,7 @@ static cellector_status select_passes(cellector_ctx *c, const double *keys, uint
     uint32_t *hist[3] = {c->sel_hist, c->sel_hist + SEL_T * 256, c->sel_hist + 2 * SEL_T * 256};
     uint64_t *state[2] = {c->sel_state, c->sel_state + 2 * SEL_T};
     HIPCHK(c, hipMemsetAsync(hist[0], 0, SEL_T * 256 * sizeof(uint32_t), c->stream));
-    uint64_t g = (n + SEL_BLOCK * 8 - 1) / (SEL_BLOCK * 8);
+    uint64_t g = (n + SEL_BLOCK * 4 - 1) / (SEL_BLOCK * 4);
     if (g > 1024) g = 1024;
     if (g < 1) g = 1;
     for (int pass = 0; pass < SEL_PASSES; pass++)

@@ -329,6 +329,7 @@ __global__ __launch_bounds__(T_THREADS, 4) void k_tile_ll(uint32_t nb, uint32_t 
 // ---------------------------------------------------------------------------------------------------------
 #define OV_NT 18  // cumulative tables cover counts 0..17; larger counts take the generic device_math path
 #define OV_NE 17  // expected terms E(n) tabulated for n = 4..17
+#define OV_FAST_N DM_CHUNK  // the cell side's fast kernel takes totals up to this (99 % of the overflow entries)
 
 // rare cases kept out of line so that the common path stays small
 __device__ __noinline__ double ov_slow_log_pmf(const double *lf, double alpha, double beta, uint32_t a, uint32_t r)
@@ -463,8 +464,9 @@ __global__ __launch_bounds__(256) void k_ovf_nmask(uint64_t L, const uint64_t *_
 // 0.26 GB of values) and slowed the tile kernel beside it more.  k_cell_finalize adds the result to the tile partials.
 // (48 VGPRs and no calls: the persistent tile workgroups leave 96 VGPRs per SIMD, so two waves of this kernel fit beside
 // them on every SIMD; the entry loop is not unrolled — a row has ~16 overflow entries and hundreds of thousands of rows
-// are in flight.  Entries with a total above OV_NE (rare; they need the generic paths: Lanczos ln_gamma beyond the factorial
-// table, the log-space fold of the expected term) are left to k_ovf_cell_slow, which visits only the rows that have one.)
+// are in flight.  Entries with a total above OV_FAST_N = 8 (1 % of them; longer products, and beyond the tables the generic
+// paths: Lanczos ln_gamma, the log-space fold of the expected term) are left to k_ovf_cell_listed, which works off two
+// short static lists of exactly those entries.)
 // The rows' entries come from a 64-row ELLPACK copy (ovf_ell: entry k of the 64 rows of a group side by side, padded with
 // all-ones to the group's longest row): a wave's loads are coalesced and every line is used once.  Reading the CSR row by
 // row, a lane per row, re-fetched each row's 128-byte line for every one of its entries (measured 2.1 GB for 0.13 GB).
@@ -485,14 +487,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(48))) void k_ov
         if (en == OVF_PAD) continue;
         const uint32_t l = ENT_IDX(en), a = ENT_ALT(en), r = ENT_REF(en), n = a + r;
         const double2 p = ab[l];
-        // masked locus: no PMFData (main.rs:556); 0/0 entry: exactly zero (Q14); a total above OV_NE: k_ovf_cell_slow
-        if (!(p.x >= 0.0) || n == 0 || n > (uint32_t)OV_NE) continue;
-        // = dm_log_bb_pmf for these totals: ln C out of the factorial table, one log per chunk of 8 factors
-        s += (lf[n] - lf[a] - lf[r]) + dm_log_beta_ratio(p.x, p.y, a, r);
-        if (EXPECTED) {
-            if (n >= 5 && n <= 8) e += etab[(uint64_t)l * 4 + (n - 5)];
-            else e += otab[(uint64_t)l * OV_ROW + OV_EOFF + (n - 4)];
+        // masked locus: no PMFData (main.rs:556); 0/0 entry: exactly zero (Q14); a total above OV_FAST_N: k_ovf_cell_listed
+        if (!(p.x >= 0.0) || n == 0 || n > (uint32_t)OV_FAST_N) continue;
+        // = dm_log_bb_pmf for these totals: ln C out of the factorial table, one log of a ratio of products of <= 8 factors
+        const double abs_ = p.x + p.y;
+        double num = 1.0, den = 1.0;
+        for (uint32_t k = 0; k < n; ++k) {
+            num *= (k < a) ? (p.x + (double)k) : (p.y + (double)(k - a));
+            den *= abs_ + (double)k;
         }
+        s += (lf[n] - lf[a] - lf[r]) + log(num / den);
+        if (EXPECTED) e += n >= 5 ? etab[(uint64_t)l * 4 + (n - 5)] : otab[(uint64_t)l * OV_ROW + OV_EOFF + (n - 4)];
     }
     o_ll[row] = s;
     if (EXPECTED) o_ell[row] = e;
@@ -523,40 +528,64 @@ __global__ __launch_bounds__(256) void k_ovf_ell_build(uint64_t n_rows, const ui
     for (uint64_t k = 0; k < kmax; k++) ell[base + k * 64] = k < len ? ovf_ent[beg + k] : OVF_PAD;
 }
 
-// rows that have an overflow entry with alt+ref > OV_NE (static; arbitrary order, every row at most once)
-__global__ __launch_bounds__(256) void k_ovf_slow_rows(uint64_t n_rows, const uint64_t *__restrict__ ovf_ptr,
-                                                       const uint64_t *__restrict__ ovf_ent, uint32_t *__restrict__ rows,
-                                                       uint32_t *__restrict__ n_out)
+// The overflow entries the fast kernel leaves out, as two small lists in row order (static): tier 0 = totals 9..OV_NE (longer
+// products; expected term still tabulated), tier 1 = totals above OV_NE (generic paths).  COUNT: entries per row and tier;
+// FILL: (row, entry) pairs at the row's offset.  A thread per row.
+__device__ __forceinline__ int ovf_tier(uint64_t en)
+{
+    const uint32_t n = ENT_ALT(en) + ENT_REF(en);
+    return n <= (uint32_t)OV_FAST_N ? -1 : (n <= (uint32_t)OV_NE ? 0 : 1);
+}
+template <bool FILL>
+__global__ __launch_bounds__(256) void k_ovf_tier_lists(uint64_t n_rows, const uint64_t *__restrict__ ovf_ptr,
+                                                        const uint64_t *__restrict__ ovf_ent,
+                                                        uint64_t *__restrict__ cnt0 /*count: out; fill: offsets*/,
+                                                        uint64_t *__restrict__ cnt1, uint32_t *__restrict__ row0,
+                                                        uint64_t *__restrict__ ent0, uint32_t *__restrict__ row1,
+                                                        uint64_t *__restrict__ ent1)
 {
     const uint64_t row = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (row >= n_rows) return;
-    bool slow = false;
+    uint64_t k0 = FILL ? cnt0[row] : 0, k1 = FILL ? cnt1[row] : 0;
     for (uint64_t i = ovf_ptr[row], end = ovf_ptr[row + 1]; i < end; i++) {
         const uint64_t en = ovf_ent[i];
-        slow |= ENT_ALT(en) + ENT_REF(en) > (uint32_t)OV_NE;
+        const int t = ovf_tier(en);
+        if (t == 0) {
+            if (FILL) { row0[k0] = (uint32_t)row; ent0[k0] = en; }
+            k0++;
+        } else if (t == 1) {
+            if (FILL) { row1[k1] = (uint32_t)row; ent1[k1] = en; }
+            k1++;
+        }
     }
-    if (slow) rows[atomicAdd(n_out, 1u)] = (uint32_t)row;
+    if (!FILL) { cnt0[row] = k0; cnt1[row] = k1; }
 }
-// their log-pmfs and expected terms (stats.rs:8-22 in the reference's log-space form), added to the row's sums
-template <bool EXPECTED>
-__global__ __launch_bounds__(256) void k_ovf_cell_slow(uint32_t n_slow, const uint32_t *__restrict__ rows,
-                                                       const uint64_t *__restrict__ ovf_ptr,
-                                                       const uint64_t *__restrict__ ovf_ent, const double2 *__restrict__ ab,
-                                                       const double *__restrict__ lf, double *__restrict__ o_ll,
-                                                       double *__restrict__ o_ell)
+// Their log-pmfs and expected terms, added to the rows' sums: a thread per listed entry; the thread of a row's FIRST listed
+// entry walks the row's run (entries of a row are adjacent, in ascending-locus order: deterministic) and updates the row.
+// GENERIC = false (tier 0): call-free and light enough to run beside the tile kernel; true (tier 1): dm_* generic paths.
+template <bool EXPECTED, bool GENERIC>
+__global__ __launch_bounds__(256) void k_ovf_cell_listed(uint64_t n_list, const uint32_t *__restrict__ rows,
+                                                         const uint64_t *__restrict__ ents, const double2 *__restrict__ ab,
+                                                         const double *__restrict__ lf, const double *__restrict__ otab,
+                                                         double *__restrict__ o_ll, double *__restrict__ o_ell)
 {
-    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= n_slow) return;
-    const uint32_t row = rows[k];
+    const uint64_t i0 = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i0 >= n_list) return;
+    const uint32_t row = rows[i0];
+    if (i0 > 0 && rows[i0 - 1] == row) return;
     double s = 0.0, e = 0.0;
-    for (uint64_t i = ovf_ptr[row], end = ovf_ptr[row + 1]; i < end; i++) {
-        const uint64_t en = ovf_ent[i];
-        const uint32_t a = ENT_ALT(en), r = ENT_REF(en), n = a + r;
-        if (n <= (uint32_t)OV_NE) continue;
-        const double2 p = ab[ENT_IDX(en)];
-        if (!(p.x >= 0.0)) continue;
-        s += dm_log_bb_pmf(lf, p.x, p.y, a, r);
-        if (EXPECTED) e += dm_expected_log_pmf(lf, p.x, p.y, n);
+    for (uint64_t i = i0; i < n_list && rows[i] == row; i++) {
+        const uint64_t en = ents[i];
+        const uint32_t l = ENT_IDX(en), a = ENT_ALT(en), r = ENT_REF(en), n = a + r;
+        const double2 p = ab[l];
+        if (!(p.x >= 0.0)) continue;  // masked locus: no PMFData (main.rs:556)
+        if (GENERIC) {
+            s += dm_log_bb_pmf(lf, p.x, p.y, a, r);
+            if (EXPECTED) e += dm_expected_log_pmf(lf, p.x, p.y, n);
+        } else {
+            s += (lf[n] - lf[a] - lf[r]) + dm_log_beta_ratio(p.x, p.y, a, r);
+            if (EXPECTED) e += otab[(uint64_t)l * OV_ROW + OV_EOFF + (n - 4)];
+        }
     }
     o_ll[row] += s;
     if (EXPECTED) o_ell[row] += e;
@@ -1274,7 +1303,7 @@ void tiled_free(cellector_ctx *c)
     dev_free(c->c4_ptr); dev_free(c->c4_ent); dev_free(c->ovc_ptr); dev_free(c->ovc_ent);
     dev_free(c->hist_all); dev_free(c->tab); dev_free(c->part); dev_free(c->ab3);
     dev_free(c->masked_cnt); dev_free(c->flag_bits); dev_free(c->ovf_tab); dev_free(c->ovf_etab);
-    dev_free(c->ovf_sum); dev_free(c->ovf_lp); dev_free(c->ovc_locus); dev_free(c->ovf_slow_rows); dev_free(c->ovf_ell_ptr); dev_free(c->ovf_ell); dev_free(c->ovf_nmask); dev_free(c->tile_work); dev_free(c->minlist); dev_free(c->hist_min); dev_free(c->roff); dev_free(c->c4r); dev_free(c->mroff); dev_free(c->mbeg);
+    dev_free(c->ovf_sum); dev_free(c->ovf_lp); dev_free(c->ovc_locus); dev_free(c->ovf_tier_row[0]); dev_free(c->ovf_tier_row[1]); dev_free(c->ovf_tier_ent[0]); dev_free(c->ovf_tier_ent[1]); dev_free(c->ovf_ell_ptr); dev_free(c->ovf_ell); dev_free(c->ovf_nmask); dev_free(c->tile_work); dev_free(c->minlist); dev_free(c->hist_min); dev_free(c->roff); dev_free(c->c4r); dev_free(c->mroff); dev_free(c->mbeg);
     c->mroff_cap = 0;
     c->tiled_ready = false;
     c->ovf_n = 0; c->n_masked_loci = 0;
@@ -1400,15 +1429,30 @@ cellector_status tiled_build(cellector_ctx *c)
                                c->ovf_ptr, c->ovf_ent, c->ovf_ell_ptr, c->ovf_ell);
         HIPCHK(c, hipGetLastError());
     }
-    CHK(dev_alloc(c, &c->ovf_slow_rows, nloc + 1));
-    c->ovf_n_slow = 0;
+    // the tier lists of the entries the fast cell-side kernel leaves out
+    c->ovf_n_tier[0] = c->ovf_n_tier[1] = 0;
     if (nloc && c->ovf_n) {
-        uint32_t *cnt = c->ovf_slow_rows + nloc;  // the list's counter lives behind it
-        HIPCHK(c, hipMemsetAsync(cnt, 0, sizeof(uint32_t), c->stream));
-        hipLaunchKernelGGL(k_ovf_slow_rows, dim3(gcap(nloc, 256, 0x7fffffffu)), dim3(256), 0, c->stream, nloc, c->ovf_ptr, c->ovf_ent,
-                           c->ovf_slow_rows, cnt);
-        HIPCHK(c, hipMemcpyAsync(&c->ovf_n_slow, cnt, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        uint64_t *cnt0 = nullptr, *cnt1 = nullptr;
+        CHK(dev_alloc(c, &cnt0, nloc + 1));
+        CHK(dev_alloc(c, &cnt1, nloc + 1));
+        HIPCHK(c, hipMemsetAsync(cnt0 + nloc, 0, 8, c->stream));
+        HIPCHK(c, hipMemsetAsync(cnt1 + nloc, 0, 8, c->stream));
+        const unsigned g = gcap(nloc, 256, 0x7fffffffu);
+        hipLaunchKernelGGL(k_ovf_tier_lists<false>, dim3(g), dim3(256), 0, c->stream, nloc, c->ovf_ptr, c->ovf_ent, cnt0, cnt1,
+                           (uint32_t *)nullptr, (uint64_t *)nullptr, (uint32_t *)nullptr, (uint64_t *)nullptr);
+        cellector_status st = dev_exclusive_scan_u64(c, cnt0, nloc + 1, &c->ovf_n_tier[0]);
+        if (st == CELLECTOR_OK) st = dev_exclusive_scan_u64(c, cnt1, nloc + 1, &c->ovf_n_tier[1]);
+        for (int t = 0; t < 2 && st == CELLECTOR_OK; t++) {
+            st = dev_alloc(c, &c->ovf_tier_row[t], c->ovf_n_tier[t]);
+            if (st == CELLECTOR_OK) st = dev_alloc(c, &c->ovf_tier_ent[t], c->ovf_n_tier[t]);
+        }
+        if (st == CELLECTOR_OK) {
+            hipLaunchKernelGGL(k_ovf_tier_lists<true>, dim3(g), dim3(256), 0, c->stream, nloc, c->ovf_ptr, c->ovf_ent, cnt0, cnt1,
+                               c->ovf_tier_row[0], c->ovf_tier_ent[0], c->ovf_tier_row[1], c->ovf_tier_ent[1]);
+            if (hipStreamSynchronize(c->stream) != hipSuccess) st = ctx_fail(c, CELLECTOR_EDEVICE, "tier list build failed");
+        }
+        dev_free(cnt0); dev_free(cnt1);
+        CHK(st);
     }
     if (L && c->ovf_n)
         hipLaunchKernelGGL(k_ovf_locus_ids, dim3(gcap(L, 4)), dim3(256), 0, c->stream, L, c->ovc_ptr, c->ovc_locus);
@@ -1465,17 +1509,23 @@ static void launch_overflow_cell(cellector_ctx *c, hipStream_t st, const double2
     const unsigned g = gcap(c->nloc, 256, 0x7fffffffu), eg = gcap(c->L * 16, 256, 0x7fffffffu);
     if (expected) {
         hipLaunchKernelGGL(k_ovf_tables_e, dim3(eg), dim3(256), 0, st, c->L, ab, c->ovf_nmask, c->ovf_tab, c->ovf_etab);
-        hipLaunchKernelGGL(k_ovf_cell_direct<true>, dim3(g), dim3(256), 0, st, c->nloc, c->ovf_ell_ptr, c->ovf_ell, ab, c->lf,
+        hipLaunchKernelGGL(k_ovf_cell_direct<true>, dim3(g), dim3(256), (size_t)c->side_lds, st, c->nloc, c->ovf_ell_ptr, c->ovf_ell, ab, c->lf,
                            c->ovf_etab, c->ovf_tab, o_ll, o_ell);
-        if (c->ovf_n_slow)
-            hipLaunchKernelGGL(k_ovf_cell_slow<true>, dim3(gcap(c->ovf_n_slow, 256)), dim3(256), 0, st, c->ovf_n_slow, c->ovf_slow_rows,
-                               c->ovf_ptr, c->ovf_ent, ab, c->lf, o_ll, o_ell);
+        if (c->ovf_n_tier[0])
+            hipLaunchKernelGGL((k_ovf_cell_listed<true, false>), dim3(gcap(c->ovf_n_tier[0], 256, 0x7fffffffu)), dim3(256), 0, st,
+                               c->ovf_n_tier[0], c->ovf_tier_row[0], c->ovf_tier_ent[0], ab, c->lf, c->ovf_tab, o_ll, o_ell);
+        if (c->ovf_n_tier[1])
+            hipLaunchKernelGGL((k_ovf_cell_listed<true, true>), dim3(gcap(c->ovf_n_tier[1], 256, 0x7fffffffu)), dim3(256), 0, st,
+                               c->ovf_n_tier[1], c->ovf_tier_row[1], c->ovf_tier_ent[1], ab, c->lf, c->ovf_tab, o_ll, o_ell);
     } else {
         hipLaunchKernelGGL(k_ovf_cell_direct<false>, dim3(g), dim3(256), 0, st, c->nloc, c->ovf_ell_ptr, c->ovf_ell, ab, c->lf,
                            c->ovf_etab, c->ovf_tab, o_ll, o_ell);
-        if (c->ovf_n_slow)
-            hipLaunchKernelGGL(k_ovf_cell_slow<false>, dim3(gcap(c->ovf_n_slow, 256)), dim3(256), 0, st, c->ovf_n_slow, c->ovf_slow_rows,
-                               c->ovf_ptr, c->ovf_ent, ab, c->lf, o_ll, o_ell);
+        if (c->ovf_n_tier[0])
+            hipLaunchKernelGGL((k_ovf_cell_listed<false, false>), dim3(gcap(c->ovf_n_tier[0], 256, 0x7fffffffu)), dim3(256), 0, st,
+                               c->ovf_n_tier[0], c->ovf_tier_row[0], c->ovf_tier_ent[0], ab, c->lf, c->ovf_tab, o_ll, o_ell);
+        if (c->ovf_n_tier[1])
+            hipLaunchKernelGGL((k_ovf_cell_listed<false, true>), dim3(gcap(c->ovf_n_tier[1], 256, 0x7fffffffu)), dim3(256), 0, st,
+                               c->ovf_n_tier[1], c->ovf_tier_row[1], c->ovf_tier_ent[1], ab, c->lf, c->ovf_tab, o_ll, o_ell);
     }
 }
 // locus side: the overflow entries' log-pmfs in by-locus order (ovf_lp), on stream `st`
@@ -1565,19 +1615,26 @@ cellector_status tiled_cell_pass(cellector_ctx *c, const double2 *ab, double *no
     const bool ovf = have_overflow(c);
     // The overflow entries' cell side runs on the side stream BESIDE the tile kernel: in the few wave slots the persistent
     // tile workgroups leave it is several times slower than alone, but it ends well inside the tile kernel's time.  In an
-    // EM iteration the locus side's values follow it there; the locus finalize waits for them (tiled_locus_pass).
-    // (overlap 0: everything in the main stream.)
+    // EM iteration the locus side's values follow on the side stream once the tile kernel is done; the locus finalize
+    // waits for them (tiled_locus_pass).  (overlap 0: everything in the main stream.)
     CHK(build_tile_tables(c, ab, 0, c->compute_expected));
     if (ovf && c->overlap) {
         CHK(side_fork(c));
         launch_overflow_cell(c, c->side, ab, 0, c->compute_expected);
         HIPCHK(c, hipEventRecord(c->ev_join, c->side));
-        if (for_em) {
+        if (for_em && c->overlap == 1) {  // the locus side's values right behind the cell side, beside the tile kernel
             launch_overflow_locus_values(c, c->side, ab);
             HIPCHK(c, hipEventRecord(c->ev_join2, c->side));
             c->ovf_locus_pending = true;
         }
         CHK(run_tile_pass(c, 0, c->compute_expected));
+        if (for_em && c->overlap == 2) {  // ... or once the tile kernel is done, beside the order statistics
+            HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
+            HIPCHK(c, hipStreamWaitEvent(c->side, c->ev_fork, 0));
+            launch_overflow_locus_values(c, c->side, ab);
+            HIPCHK(c, hipEventRecord(c->ev_join2, c->side));
+            c->ovf_locus_pending = true;
+        }
         HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
     } else {
         if (ovf) {
