@@ -1320,14 +1320,26 @@ cellector_status tiled_build(cellector_ctx *c)
     if (c->t_nj == 0) c->t_nj = 1;
     // Chunk groups: a multiple of the 8 XCDs (workgroup i runs on XCD i mod 8, so a group's workgroups share one L2).  The
     // tile kernel runs one persistent workgroup per CU, each bound to a group and fetching columns of T_SB_MAX cell
-    // blocks: 8 groups when there are at least CUs / 8 columns, more groups for a smaller shard so that every CU still
-    // gets a (group, column) pair — at the price of one more partial sum per cell and group.
+    // blocks; more groups mean shorter turns per column (better balance when there are few columns per workgroup) at the
+    // price of one more partial sum per cell and group.
     {
         int ncu = 256;
         (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, c->device);
         const uint64_t cols = (c->t_nb + T_SB_MAX - 1) / T_SB_MAX;
-        uint64_t groups = T_GROUPS * (((uint64_t)ncu + cols * T_GROUPS - 1) / (cols * T_GROUPS));
-        if (groups > T_GROUPS_MAX) groups = T_GROUPS_MAX;
+        // every workgroup of a group walks the group's chunks once per column it fetches: the kernel takes
+        // rounds(g) x chunks(g) chunk-steps with rounds = ceil(columns / workgroups per group).  Take the multiple of 8
+        // with the shortest makespan (e.g. 49 columns: 8 groups need 2 rounds of 66 chunk-steps, 24 groups 5 rounds of 22),
+        // charging 1 % per extra 8 groups for the additional partial sums.
+        uint64_t groups = T_GROUPS;
+        double best = 1e300;
+        for (uint64_t g = T_GROUPS; g <= T_GROUPS_MAX && g <= (uint64_t)c->t_nj; g += T_GROUPS) {
+            uint64_t per = (uint64_t)ncu / g;
+            if (per < 1) per = 1;
+            if (per > cols) per = cols;
+            const uint64_t rounds = (cols + per - 1) / per, chunks = ((uint64_t)c->t_nj + g - 1) / g;
+            const double cost = (double)(rounds * chunks) * (1.0 + 0.01 * (double)(g / T_GROUPS - 1));
+            if (cost < best) { best = cost; groups = g; }
+        }
         if (groups > c->t_nj) groups = c->t_nj;
         c->t_groups = (uint32_t)groups;
     }
@@ -1582,7 +1594,7 @@ static cellector_status run_tile_pass(cellector_ctx *c, int set, bool expected)
     int ncu = 256;
     (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, c->device);
     int sb = T_SB_MAX;
-    while (sb > 2 && (uint64_t)((c->t_nb + sb - 1) / sb) * c->t_groups < (uint64_t)ncu) sb >>= 1;
+    while (sb > 2 && (uint64_t)((c->t_nb + sb - 1) / sb) * c->t_groups * 10 < (uint64_t)ncu * 9) sb >>= 1;  // < 90 % of the CUs busy
     const uint32_t n_cols = (c->t_nb + sb - 1) / sb;
     // persistent workgroups: one per CU, an equal number for every chunk group, never more than there are columns
     uint32_t per_group = (uint32_t)ncu / c->t_groups;
