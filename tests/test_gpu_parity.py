@@ -192,7 +192,7 @@ def test_overflow_side_stream_equals_in_stream(mods):
     al = np.where(big, al * rng.integers(1, 12, len(al)), al).astype(np.uint32)
     re = np.where(big, re * rng.integers(1, 12, len(re)), re).astype(np.uint32)
     outs = []
-    for ov in (1, 0):
+    for ov in (1, 0, 2):  # beside the lookup kernel (default) / in one stream / locus-side values after the lookup kernel
         g = mods["Cellector"](0)
         g.set_option("overlap", ov)
         g.load_coo(L, N, lo, ce, al, re)
@@ -208,15 +208,16 @@ def test_overflow_side_stream_equals_in_stream(mods):
         outs.append((run, pg))
         g.close()
         o.close()
-    (run_a, post_a), (run_b, post_b) = outs
-    assert len(run_a) == len(run_b)
-    for (ca, la), (cb, lb) in zip(run_a, run_b):
-        for k in ca:
-            assert np.array_equal(ca[k], cb[k]), k
-        for k in la:
-            assert np.array_equal(la[k], lb[k]), k
-    for k in post_a:
-        assert np.array_equal(post_a[k], post_b[k]), k
+    run_a, post_a = outs[0]
+    for run_b, post_b in outs[1:]:
+        assert len(run_a) == len(run_b)
+        for (ca, la), (cb, lb) in zip(run_a, run_b):
+            for k in ca:
+                assert np.array_equal(ca[k], cb[k]), k
+            for k in la:
+                assert np.array_equal(la[k], lb[k]), k
+        for k in post_a:
+            assert np.array_equal(post_a[k], post_b[k]), k
 
 
 def test_ll_pass_under_caller_alpha_beta_and_mask(mods):
