@@ -440,7 +440,8 @@ cellector_status cellector_em_begin(cellector_ctx *c)
     READY(c);
     REQUIRE(c, c->em_phase == 0, "em_begin: previous iteration not finished");
     SETDEV(c);
-    CHK(launch_alpha_beta(c));
+    // engine 2 forms alpha/beta inside its first kernel (k_build_tables); an empty shard has no cell pass at all
+    if (c->engine != 2 || c->nloc == 0) CHK(launch_alpha_beta(c));
     if (c->nloc != c->total_cells)  // other shards' slices must be zero before the sum-exchange
         HIPCHK(c, hipMemsetAsync(c->x_norm, 0, c->total_cells * 8, c->stream));
     cellector_status st = c->engine == 2 ? tiled_cell_pass(c, c->ab, c->x_norm + c->cell_begin, true)

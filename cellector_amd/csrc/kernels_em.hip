@@ -98,7 +98,7 @@ __global__ __launch_bounds__(BLOCK) void k_cell_ll(uint64_t n_rows, const uint64
 __global__ __launch_bounds__(FLAG_THREADS) void k_flag(uint64_t n, const double *__restrict__ norm, const double *__restrict__ d_thr,
                                                        const uint8_t *__restrict__ old_flags, uint8_t *__restrict__ new_flags,
                                                        double *__restrict__ counters, uint32_t *__restrict__ minlist /*may be null*/,
-                                                       uint32_t *__restrict__ n_min)
+                                                       uint32_t *__restrict__ n_min, uint32_t *__restrict__ flag_bits /*with minlist*/)
 {
     __shared__ uint32_t s_wave[FLAG_THREADS / 64];
     __shared__ uint32_t s_base;
@@ -152,6 +152,8 @@ __global__ __launch_bounds__(FLAG_THREADS) void k_flag(uint64_t n, const double 
         const unsigned long long m = __ballot(nf);
         if (nf) minlist[pos + (uint32_t)__popcll(m & ((1ull << (threadIdx.x & 63)) - 1ull))] = (uint32_t)i;
         pos += (uint32_t)__popcll(m);
+        // the exclusion set as a bitmask too (locus pass): the wave's 64 cells are two words (i is 64-aligned in lane 0)
+        if ((threadIdx.x & 31) == 0 && i < end) flag_bits[i >> 5] = (uint32_t)(m >> (threadIdx.x & 32));
     }
 }
 
@@ -383,7 +385,7 @@ cellector_status launch_flag(cellector_ctx *c, const double *d_thr)
     if (c->nloc == 0) return CELLECTOR_OK;
     hipLaunchKernelGGL(k_flag, dim3(grid_for(c->nloc, FLAG_THREADS * 4, 256)), dim3(FLAG_THREADS), 0, c->stream, c->nloc,
                        c->x_norm + c->cell_begin, d_thr, c->flags, c->flags_new, c->x_locus + LB_PLANES * c->L,
-                       c->tiled_ready ? c->minlist : (uint32_t *)nullptr, c->d_counters + DC_N_MIN);
+                       c->tiled_ready ? c->minlist : (uint32_t *)nullptr, c->d_counters + DC_N_MIN, c->flag_bits);
     HIPCHK(c, hipGetLastError());
     return CELLECTOR_OK;
 }

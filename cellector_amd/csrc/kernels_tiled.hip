@@ -67,14 +67,39 @@ __device__ __forceinline__ uint32_t ent_code(uint64_t e)
 // straight into LDS.  PAIRS: element = (log-pmf of the code, expected term of the code's n) as double2; else the
 // log-pmf alone.  Zero for masked loci (alpha < 0), for the padding beyond L and in row T_NCODE.
 // ---------------------------------------------------------------------------------------------------------
+// In an EM iteration the kernel is the iteration's FIRST one: it then also forms alpha/beta (init_alpha_betas,
+// main.rs:598-611: alpha_l = (S_alt_l + 1) - sum over excluded cells, the subtrahend being the all-reduced ALT_MIN plane of
+// the previous iteration; masked loci get alpha = -1), stores them for the other kernels and resets the iteration's counters.
+struct ab_src_t {
+    const double *s_alt, *s_ref, *alt_min, *ref_min;  // null s_alt: alpha/beta are read from `ab`
+    const uint8_t *mask;
+    double2 *ab_out;
+    double *xl_counters;
+    uint32_t *d_counters, *tile_work;
+    uint32_t n_work;
+};
 template <bool PAIRS>
 __global__ void k_build_tables(uint64_t L, uint32_t nj, const double2 *__restrict__ ab, const double *__restrict__ lf,
-                               double *__restrict__ tab)
+                               double *__restrict__ tab, ab_src_t src)
 {
+    if (src.s_alt && blockIdx.x == 0) {
+        if (threadIdx.x < LC_COUNTERS) src.xl_counters[threadIdx.x] = 0.0;
+        if (threadIdx.x < 8) src.d_counters[threadIdx.x] = 0u;
+        for (uint32_t i = threadIdx.x; i < src.n_work; i += blockDim.x) src.tile_work[i] = 0u;
+    }
     const uint64_t l = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (l >= (uint64_t)nj * T_BL) return;
     double2 p = make_double2(-1.0, -1.0);
-    if (l < L) p = ab[l];
+    if (l < L) {
+        if (src.s_alt) {
+            p.x = (src.s_alt[l] + 1.0) - src.alt_min[l];
+            p.y = (src.s_ref[l] + 1.0) - src.ref_min[l];
+            if (!src.mask[l]) p.x = p.y = -1.0;
+            src.ab_out[l] = p;
+        } else {
+            p = ab[l];
+        }
+    }
     const bool live = p.x >= 0.0;
     double ex[T_K + 1];
 #pragma unroll
@@ -650,14 +675,6 @@ __device__ __forceinline__ void c4_write1(uint32_t *__restrict__ base, uint64_t 
         b[0] = (uint8_t)v; b[1] = (uint8_t)(v >> 8); b[2] = (uint8_t)(v >> 16);
     }
 }
-__global__ void k_pack_flag_bits(uint64_t n, const uint8_t *__restrict__ flags, uint32_t *__restrict__ bits)
-{
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const unsigned long long m = __ballot(i < n && flags[i] != 0);
-    const uint64_t w = i >> 5;
-    if ((threadIdx.x & 31) == 0 && w * 32 < n) bits[w] = (uint32_t)(m >> (threadIdx.x & 32));
-}
-
 // Form of the locus pass, decided on the device from this shard's exclusion-set size (see k_minority_hist below)
 #define LM_NUM 1  // minority-driven when n_min / nloc <= LM_NUM / LM_DEN
 #define LM_DEN 8
@@ -1566,15 +1583,25 @@ static cellector_status side_join(cellector_ctx *c)
 }
 
 // the chunk tables of one pass
-static cellector_status build_tile_tables(cellector_ctx *c, const double2 *ab, int set, bool expected)
+static cellector_status build_tile_tables(cellector_ctx *c, const double2 *ab, int set, bool expected, bool form_ab = false)
 {
     const uint64_t tab_elems = (uint64_t)c->t_nj * TAB_ELEMS;
     double *tab = expected ? c->tab + 3 * tab_elems : c->tab + (uint64_t)set * tab_elems;
     const unsigned tgrid = gcap((uint64_t)c->t_nj * T_BL, 256);
+    ab_src_t src = {};
+    if (form_ab) {  // first kernel of an EM iteration: alpha/beta from the exchanged tallies, counters reset
+        const uint64_t L = c->L;
+        src.s_alt = c->s_alt; src.s_ref = c->s_ref;
+        src.alt_min = c->x_locus + LB_ALT_MIN * L; src.ref_min = c->x_locus + LB_REF_MIN * L;
+        src.mask = c->mask; src.ab_out = c->ab;
+        src.xl_counters = c->x_locus + (uint64_t)LB_PLANES * L; src.d_counters = c->d_counters;
+        src.tile_work = c->tile_work; src.n_work = 3u * T_GROUPS_MAX;
+        c->work_zeroed = true;
+    }
     if (expected)
-        hipLaunchKernelGGL(k_build_tables<true>, dim3(tgrid), dim3(256), 0, c->stream, c->L, c->t_nj, ab, c->lf, tab);
+        hipLaunchKernelGGL(k_build_tables<true>, dim3(tgrid), dim3(256), 0, c->stream, c->L, c->t_nj, ab, c->lf, tab, src);
     else
-        hipLaunchKernelGGL(k_build_tables<false>, dim3(tgrid), dim3(256), 0, c->stream, c->L, c->t_nj, ab, c->lf, tab);
+        hipLaunchKernelGGL(k_build_tables<false>, dim3(tgrid), dim3(256), 0, c->stream, c->L, c->t_nj, ab, c->lf, tab, src);
     if (set == 0) {  // the locus pass of this iteration reads the log-pmfs of the EM pass' table
         c->tab_em = tab;
         c->tab_em_stride = expected ? 2 : 1;
@@ -1629,7 +1656,7 @@ cellector_status tiled_cell_pass(cellector_ctx *c, const double2 *ab, double *no
     // tile workgroups leave it is several times slower than alone, but it ends well inside the tile kernel's time.  In an
     // EM iteration the locus side's values follow on the side stream once the tile kernel is done; the locus finalize
     // waits for them (tiled_locus_pass).  (overlap 0: everything in the main stream.)
-    CHK(build_tile_tables(c, ab, 0, c->compute_expected));
+    CHK(build_tile_tables(c, ab, 0, c->compute_expected, for_em));
     if (ovf && c->overlap) {
         CHK(side_fork(c));
         launch_overflow_cell(c, c->side, ab, 0, c->compute_expected);
@@ -1674,9 +1701,7 @@ cellector_status tiled_locus_pass(cellector_ctx *c)
     if (c->L == 0) return CELLECTOR_OK;
     timer_begin(c, CELLECTOR_K_LOCUS_STATS);
     const uint32_t words = (uint32_t)((c->nloc + 31) / 32);
-    if (c->nloc)
-        hipLaunchKernelGGL(k_pack_flag_bits, dim3(gcap(((c->nloc + 63) / 64) * 64, 256)), dim3(256), 0, c->stream, c->nloc,
-                           c->flags_new, c->flag_bits);
+    // (k_flag wrote the exclusion bitmask flag_bits along with the flags)
     const size_t lds = (size_t)words * 4;
     int ncu = 256;
     (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, c->device);
