@@ -269,6 +269,15 @@ cellector_status cellector_ingest_synthetic(cellector_ctx *c, uint64_t total_loc
     return CELLECTOR_OK;
 }
 
+cellector_status cellector_write_staged_mtx(cellector_ctx *c, const char *alt_path, const char *ref_path)
+{
+    if (!c) return CELLECTOR_EINVAL;
+    REQUIRE(c, alt_path && ref_path, "null path");
+    REQUIRE(c, c->state != cellector_ctx::ST_EMPTY, "write_staged_mtx without a staged matrix");
+    SETDEV(c);
+    return synth_write_mtx(c, alt_path, ref_path);
+}
+
 cellector_status cellector_ingest_finish(cellector_ctx *c, uint64_t min_alt, uint64_t min_ref)
 {
     if (!c) return CELLECTOR_EINVAL;

@@ -219,6 +219,7 @@ cellector_status ingest_pass1(cellector_ctx *c);
 cellector_status ingest_build(cellector_ctx *c, uint64_t min_alt, uint64_t min_ref);
 cellector_status synth_generate(cellector_ctx *c, double density, uint64_t seed, double minority_fraction,
                                 double doublet_fraction);
+cellector_status synth_write_mtx(cellector_ctx *c, const char *alt_path, const char *ref_path);
 // device helpers
 cellector_status dev_exclusive_scan_u64(cellector_ctx *c, uint64_t *data, uint64_t n, uint64_t *total_out_host);
 cellector_status dev_sort_pairs_u32_u64(cellector_ctx *c, uint32_t *keys_in, uint32_t *keys_out,

@@ -172,3 +172,79 @@ cellector_status synth_generate(cellector_ctx *c, double density, uint64_t seed,
     dev_free(tiles);
     return CELLECTOR_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// Benchmark utility (not a reference seam): the staged matrix as vartrix-style MatrixMarket text, `locus cell count` lines,
+// 1-based, file order — so that BASELINE-sized inputs for the text path can be produced in seconds (tools/e2e_bench.py).
+// Lines are formatted on the device in chunks: lengths -> exclusive scan -> characters, then copied out and written.
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t dec_digits(uint32_t v)
+{
+    uint32_t d = 1;
+    while (v >= 10u) { v /= 10u; d++; }
+    return d;
+}
+__device__ __forceinline__ uint8_t *put_dec(uint8_t *p, uint32_t v, uint32_t d)
+{
+    for (uint32_t k = d; k-- > 0;) { p[k] = (uint8_t)('0' + v % 10u); v /= 10u; }
+    return p + d;
+}
+template <bool FILL>
+__global__ __launch_bounds__(256) void k_mtx_lines(uint64_t n, uint64_t cell_begin, const uint32_t *__restrict__ locus,
+                                                   const uint32_t *__restrict__ cell, const uint16_t *__restrict__ val,
+                                                   uint64_t *__restrict__ len_or_off, uint8_t *__restrict__ out)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t a = locus[i] + 1u, b = (uint32_t)(cell_begin + cell[i]) + 1u, v = val[i];
+    const uint32_t da = dec_digits(a), db = dec_digits(b), dv = dec_digits(v);
+    if (!FILL) {
+        len_or_off[i] = da + db + dv + 3u;
+        return;
+    }
+    uint8_t *p = out + len_or_off[i];
+    p = put_dec(p, a, da); *p++ = ' ';
+    p = put_dec(p, b, db); *p++ = ' ';
+    p = put_dec(p, v, dv); *p = '\n';
+}
+
+cellector_status synth_write_mtx(cellector_ctx *c, const char *alt_path, const char *ref_path)
+{
+    if (!c->coo_locus && c->coo_n) return ctx_fail(c, CELLECTOR_EINVAL, "write_staged_mtx: no staged matrix (option keep_coo=1)");
+    const uint64_t n = c->coo_n, CH = 1ull << 25;  // 32M lines per chunk: at most 26 bytes each
+    FILE *f[2] = {fopen(alt_path, "wb"), fopen(ref_path, "wb")};
+    uint64_t *off = nullptr;
+    uint8_t *dbuf = nullptr, *hbuf = nullptr;
+    cellector_status st = CELLECTOR_OK;
+    if (!f[0] || !f[1]) st = ctx_fail(c, CELLECTOR_EIO, "write_staged_mtx: cannot create %s", f[0] ? ref_path : alt_path);
+    if (st == CELLECTOR_OK) st = dev_alloc(c, &off, CH + 1);
+    if (st == CELLECTOR_OK) st = dev_alloc(c, &dbuf, CH * 26);
+    if (st == CELLECTOR_OK && hipHostMalloc((void **)&hbuf, CH * 26) != hipSuccess) st = ctx_fail(c, CELLECTOR_ENOMEM, "pinned buffer");
+    for (int k = 0; k < 2 && st == CELLECTOR_OK; k++)
+        fprintf(f[k], "%%%%MatrixMarket matrix coordinate real general\n%% written by sprs\n%llu %llu %llu\n",
+                (unsigned long long)c->total_loci, (unsigned long long)c->total_cells, (unsigned long long)n);
+    for (uint64_t i0 = 0; i0 < n && st == CELLECTOR_OK; i0 += CH) {
+        const uint64_t m = n - i0 < CH ? n - i0 : CH;
+        const unsigned g = (unsigned)((m + 255) / 256);
+        for (int k = 0; k < 2 && st == CELLECTOR_OK; k++) {
+            const uint16_t *val = (k == 0 ? c->coo_alt : c->coo_ref) + i0;
+            uint64_t bytes = 0;
+            hipError_t e = hipMemsetAsync(off + m, 0, 8, c->stream);
+            hipLaunchKernelGGL(k_mtx_lines<false>, dim3(g), dim3(256), 0, c->stream, m, c->cell_begin, c->coo_locus + i0,
+                               c->coo_cell + i0, val, off, (uint8_t *)nullptr);
+            if (e == hipSuccess) st = dev_exclusive_scan_u64(c, off, m + 1, &bytes);
+            if (st != CELLECTOR_OK) break;
+            hipLaunchKernelGGL(k_mtx_lines<true>, dim3(g), dim3(256), 0, c->stream, m, c->cell_begin, c->coo_locus + i0,
+                               c->coo_cell + i0, val, off, dbuf);
+            if (e == hipSuccess) e = hipMemcpyAsync(hbuf, dbuf, bytes, hipMemcpyDeviceToHost, c->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+            if (e != hipSuccess) { st = ctx_fail(c, CELLECTOR_EDEVICE, "write_staged_mtx: %s", hipGetErrorString(e)); break; }
+            if (fwrite(hbuf, 1, bytes, f[k]) != bytes) st = ctx_fail(c, CELLECTOR_EIO, "write_staged_mtx: short write");
+        }
+    }
+    for (int k = 0; k < 2; k++)
+        if (f[k] && fclose(f[k]) != 0 && st == CELLECTOR_OK) st = ctx_fail(c, CELLECTOR_EIO, "write_staged_mtx: close failed");
+    dev_free(off); dev_free(dbuf);
+    if (hbuf) (void)hipHostFree(hbuf);
+    return st;
+}

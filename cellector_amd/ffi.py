@@ -28,6 +28,7 @@ SIGNATURES = {
     "cellector_ingest_mtx": (_i, [_vp, _cp, _cp]),
     "cellector_ingest_coo": (_i, [_vp, _u64, _u64, _u64, _vp, _vp, _vp, _vp]),
     "cellector_ingest_synthetic": (_i, [_vp, _u64, _u64, _d, _u64, _d, _d]),
+    "cellector_write_staged_mtx": (_i, [_vp, C.c_char_p, C.c_char_p]),
     "cellector_ingest_finish": (_i, [_vp, _u64, _u64]),
     "cellector_load_mtx": (_i, [_vp, _cp, _cp, _u64, _u64]),
     "cellector_load_coo": (_i, [_vp, _u64, _u64, _u64, _vp, _vp, _vp, _vp, _u64, _u64]),
@@ -156,6 +157,10 @@ class Cellector:
 
     def ingest_finish(self, min_alt=4, min_ref=4):
         self._ck(self._lib.cellector_ingest_finish(self.h, int(min_alt), int(min_ref)))
+
+    def write_staged_mtx(self, alt_path, ref_path):
+        """Benchmark utility: the staged matrix as a vartrix-style text pair (needs option keep_coo=1)."""
+        self._ck(self._lib.cellector_write_staged_mtx(self.h, str(alt_path).encode(), str(ref_path).encode()))
 
     def load_mtx(self, alt_path, ref_path, min_alt=4, min_ref=4):
         self._ck(self._lib.cellector_load_mtx(self.h, str(alt_path).encode(), str(ref_path).encode(), min_alt, min_ref))

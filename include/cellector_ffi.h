@@ -81,6 +81,10 @@ cellector_status cellector_ingest_coo(cellector_ctx *ctx, uint64_t total_loci, u
 cellector_status cellector_ingest_synthetic(cellector_ctx *ctx, uint64_t total_loci,
                                             uint64_t total_cells, double density, uint64_t seed,
                                             double minority_fraction, double doublet_fraction);
+/* Benchmark utility, not a reference seam: writes the staged matrix (any ingest, option keep_coo=1)
+ * as a vartrix-style alt.mtx / ref.mtx text pair (3-line header, `locus cell count`, 1-based, file
+ * order), formatted on the device — BASELINE-sized inputs for the text path in seconds. */
+cellector_status cellector_write_staged_mtx(cellector_ctx *ctx, const char *alt_path, const char *ref_path);
 /* >>> multi-shard: all-reduce CELLECTOR_XCHG_PASS1 here <<< */
 /* Phase 2 — locus filter `cells_ref >= min_ref && cells_alt >= min_alt` (load_data.rs:273),
  * compaction, CSR (by cell) + CSC (by locus) build on the device (pass 2, load_data.rs:151-174). */

@@ -29,6 +29,9 @@ def main():
     ap.add_argument("--density", type=float, default=0.01)
     ap.add_argument("--cpu-threads", type=int, default=1)
     ap.add_argument("--no-oracle", action="store_true")
+    ap.add_argument("--device-writer", action="store_true",
+                    help="format the text files on the device (cellector_write_staged_mtx): for BASELINE-sized inputs")
+    ap.add_argument("--tmp", default=None, help="directory for the input / output files (default: a temp dir)")
     args = ap.parse_args()
     import ctypes
     from cellector_amd import Cellector, synth
@@ -38,25 +41,35 @@ def main():
     fast = ctypes.CDLL(lib_path)
     fast.fastmtx_write.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_uint64] + [ctypes.c_void_p] * 3
     N, L = args.cells, args.loci
-    with Cellector(0) as g:
-        g.load_synthetic(L, N, args.density, seed=4, min_alt=0, min_ref=0)
-        rp, ent = g.csr_rows(0, N)
-    cell = np.repeat(np.arange(N, dtype=np.int64), np.diff(rp.astype(np.int64)))
-    locus = (ent & np.uint64(0xFFFFFFFF)).astype(np.int64)
-    alt = ((ent >> np.uint64(32)) & np.uint64(0xFFFF)).astype(np.int64)
-    ref = (ent >> np.uint64(48)).astype(np.int64)
-    order = np.argsort(locus, kind="stable")
-    locus, cell, alt, ref = locus[order] + 1, cell[order] + 1, alt[order], ref[order]
-    d = tempfile.mkdtemp(prefix="cellector_e2e_")
-    paths = {}
-    for name, vals in (("alt", alt), ("ref", ref)):
-        p = os.path.join(d, name + ".mtx")
-        hdr = f"%%MatrixMarket matrix coordinate real general\n% written by sprs\n{L} {N} {len(locus)}\n"
-        vals = np.ascontiguousarray(vals)
-        assert fast.fastmtx_write(p.encode(), hdr.encode(), len(locus), locus.ctypes.data, cell.ctypes.data, vals.ctypes.data) == 0
-        paths[name] = p
-    n_entries = int(len(locus))
-    del locus, cell, alt, ref, order
+    d = tempfile.mkdtemp(prefix="cellector_e2e_", dir=args.tmp)
+    paths = {name: os.path.join(d, name + ".mtx") for name in ("alt", "ref")}
+    t_write = time.perf_counter()
+    if args.device_writer:
+        with Cellector(0) as g:
+            g.set_option("keep_coo", 1)
+            g.ingest_synthetic(L, N, args.density, seed=4)
+            g.write_staged_mtx(paths["alt"], paths["ref"])
+        with open(paths["ref"], "rb") as f:
+            f.readline(); f.readline()
+            n_entries = int(f.readline().split()[2])
+    else:
+        with Cellector(0) as g:
+            g.load_synthetic(L, N, args.density, seed=4, min_alt=0, min_ref=0)
+            rp, ent = g.csr_rows(0, N)
+        cell = np.repeat(np.arange(N, dtype=np.int64), np.diff(rp.astype(np.int64)))
+        locus = (ent & np.uint64(0xFFFFFFFF)).astype(np.int64)
+        alt = ((ent >> np.uint64(32)) & np.uint64(0xFFFF)).astype(np.int64)
+        ref = (ent >> np.uint64(48)).astype(np.int64)
+        order = np.argsort(locus, kind="stable")
+        locus, cell, alt, ref = locus[order] + 1, cell[order] + 1, alt[order], ref[order]
+        for name, vals in (("alt", alt), ("ref", ref)):
+            hdr = f"%%MatrixMarket matrix coordinate real general\n% written by sprs\n{L} {N} {len(locus)}\n"
+            vals = np.ascontiguousarray(vals)
+            assert fast.fastmtx_write(paths[name].encode(), hdr.encode(), len(locus), locus.ctypes.data, cell.ctypes.data,
+                                      vals.ctypes.data) == 0
+        n_entries = int(len(locus))
+        del locus, cell, alt, ref, order
+    t_write = time.perf_counter() - t_write
     bc = os.path.join(d, "barcodes.tsv")
     synth.write_barcodes(bc, N)
     vcf = os.path.join(d, "variants.vcf")
@@ -77,6 +90,7 @@ def main():
     out_bytes = sum(os.path.getsize(os.path.join(out_dir, f)) for f in os.listdir(out_dir))
     res = {"workload": f"{N} cells x {L} loci, density {args.density}: text .mtx pair + barcodes + VCF -> all TSVs + cellector.vcf",
            "entries": n_entries, "text_bytes": int(sum(os.path.getsize(p) for p in paths.values())),
+           "inputs_written_s": t_write, "device_writer": bool(args.device_writer),
            "em_iterations": n_iter, "output_bytes": int(out_bytes),
            "gpu_cli_wall_s": times[1], "gpu_cli_first_run_s": times[0]}
     if not args.no_oracle:
