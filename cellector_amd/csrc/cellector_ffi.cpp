@@ -6,6 +6,11 @@
 #include <cstdio>
 #include <cstring>
 
+#include <chrono>
+#include <vector>
+#include <unordered_map>
+#include <mutex>
+
 #include "ctx.h"
 
 cellector_status ctx_fail(const cellector_ctx *c, cellector_status s, const char *fmt, ...)
@@ -90,6 +95,83 @@ static bool create_side_stream(hipStream_t *out)
     } while (0)
 #define SETDEV(c) HIPCHK((c), hipSetDevice((c)->device))
 
+// ---- caching layer under dev_alloc / dev_free (see ctx.h) -------------------------------------------------------
+namespace {
+struct DevBlock { void *p; size_t bytes; int device; };
+std::mutex g_cache_mu;
+std::vector<DevBlock> g_cache_free;                 // freed, still mapped
+std::unordered_map<void *, DevBlock> g_cache_live;  // handed out by dev_cache_malloc
+const size_t CACHE_MIN = 64ull << 20;               // smaller blocks go straight to the driver
+}  // namespace
+
+hipError_t dev_cache_malloc(void **p, size_t bytes)
+{
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (bytes >= CACHE_MIN) {
+        std::lock_guard<std::mutex> lk(g_cache_mu);
+        size_t best = (size_t)-1;
+        for (size_t i = 0; i < g_cache_free.size(); i++) {
+            const DevBlock &b = g_cache_free[i];
+            // fits, wastes at most a quarter, and is the tightest such block
+            if (b.device == dev && b.bytes >= bytes && b.bytes - bytes <= bytes / 4 &&
+                (best == (size_t)-1 || b.bytes < g_cache_free[best].bytes))
+                best = i;
+        }
+        if (best != (size_t)-1) {
+            DevBlock b = g_cache_free[best];
+            g_cache_free.erase(g_cache_free.begin() + (long)best);
+            g_cache_live[b.p] = b;
+            *p = b.p;
+            return hipSuccess;
+        }
+    }
+    hipError_t e = hipMalloc(p, bytes);
+    if (e != hipSuccess) {  // out of memory: give the cached blocks back and try once more
+        (void)hipGetLastError();
+        dev_cache_trim();
+        e = hipMalloc(p, bytes);
+    }
+    if (e == hipSuccess && bytes >= CACHE_MIN) {
+        std::lock_guard<std::mutex> lk(g_cache_mu);
+        g_cache_live[*p] = DevBlock{*p, bytes, dev};
+    }
+    return e;
+}
+
+void dev_cache_free(void *p)
+{
+    if (!p) return;
+    {
+        std::lock_guard<std::mutex> lk(g_cache_mu);
+        auto it = g_cache_live.find(p);
+        if (it != g_cache_live.end()) {
+            // hipFree would have waited for the device; a block handed out again must not still be in use either
+            (void)hipDeviceSynchronize();
+            g_cache_free.push_back(it->second);
+            g_cache_live.erase(it);
+            return;
+        }
+    }
+    (void)hipFree(p);
+}
+
+void dev_cache_trim()
+{
+    std::vector<DevBlock> blocks;
+    {
+        std::lock_guard<std::mutex> lk(g_cache_mu);
+        blocks.swap(g_cache_free);
+    }
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    for (const DevBlock &b : blocks) {
+        (void)hipSetDevice(b.device);
+        (void)hipFree(b.p);
+    }
+    (void)hipSetDevice(cur);
+}
+
 extern "C" {
 
 const char *cellector_version(void) { return "cellector_amd 0.1 (gfx950)"; }
@@ -145,6 +227,7 @@ void cellector_destroy(cellector_ctx *c)
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->ev_join2) (void)hipEventDestroy(c->ev_join2);
     delete c;
+    dev_cache_trim();
 }
 
 const char *cellector_last_error(const cellector_ctx *c) { return c ? c->err.c_str() : "null ctx"; }
@@ -241,17 +324,30 @@ cellector_status cellector_ingest_coo(cellector_ctx *c, uint64_t total_loci, uin
     return CELLECTOR_OK;
 }
 
+// CELLECTOR_TIMING=1: phase wall times of the ingest on stderr
+static double lap_s(std::chrono::steady_clock::time_point *t)
+{
+    const auto now = std::chrono::steady_clock::now();
+    const double s = std::chrono::duration<double>(now - *t).count();
+    *t = now;
+    return s;
+}
+
 cellector_status cellector_ingest_mtx(cellector_ctx *c, const char *alt_path, const char *ref_path)
 {
     if (!c) return CELLECTOR_EINVAL;
     REQUIRE(c, alt_path && ref_path, "null path");
+    const bool timing = getenv("CELLECTOR_TIMING") != nullptr;
+    auto t = std::chrono::steady_clock::now();
     MtxInput *in = nullptr;
     uint64_t tl = 0, tc = 0;
     CHK(mtx_input_open(c, alt_path, ref_path, &in, &tl, &tc));
+    if (timing) fprintf(stderr, "[timing]   open / inflate          %8.3f s\n", lap_s(&t));
     cellector_status s = begin_ingest(c, tl, tc);
     if (s == CELLECTOR_OK) s = ingest_stage_mtx_device(c, in);  // tokenised and converted on the GPU
     mtx_input_close(in);
     CHK(s);
+    if (timing) fprintf(stderr, "[timing]   upload + device parse   %8.3f s\n", lap_s(&t));
     CHK(ingest_pass1(c));
     c->state = cellector_ctx::ST_STAGED;
     return CELLECTOR_OK;
@@ -283,7 +379,10 @@ cellector_status cellector_ingest_finish(cellector_ctx *c, uint64_t min_alt, uin
     if (!c) return CELLECTOR_EINVAL;
     REQUIRE(c, c->state == cellector_ctx::ST_STAGED, "ingest_finish without a staged matrix");
     SETDEV(c);
+    const bool timing = getenv("CELLECTOR_TIMING") != nullptr;
+    auto t = std::chrono::steady_clock::now();
     CHK(ingest_build(c, min_alt, min_ref));
+    if (timing) fprintf(stderr, "[timing]   CSC / CSR build         %8.3f s\n", lap_s(&t));
     const uint64_t L = c->L, n = c->nloc;
     CHK(dev_alloc(c, &c->ab, L)); CHK(dev_alloc(c, &c->ab6, 8 * L));
     CHK(dev_alloc(c, &c->mask, L)); CHK(dev_alloc(c, &c->mask_next, L));
@@ -308,6 +407,8 @@ cellector_status cellector_ingest_finish(cellector_ctx *c, uint64_t min_alt, uin
     HIPCHK(c, hipMemsetAsync(c->x_locus, 0, need_locus * 8, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (c->engine == 2) CHK(tiled_build(c));
+    if (timing) fprintf(stderr, "[timing]   tiled layouts           %8.3f s\n", lap_s(&t));
+    dev_cache_trim();  // the ingest's big temporaries are done: hand the cached blocks back
     c->state = cellector_ctx::ST_READY;
     c->em_phase = 0; c->iteration = 0; c->have_iter = false; c->n_excluded_global = 0;
     return CELLECTOR_OK;

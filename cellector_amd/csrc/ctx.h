@@ -174,11 +174,19 @@ cellector_status ctx_fail(const cellector_ctx *c, cellector_status s, const char
         if (s__ != CELLECTOR_OK) return s__;                                                     \
     } while (0)
 
+// Device memory goes through a small caching layer (cellector_ffi.cpp): mapping fresh VRAM costs ~30-50 ms per GB on
+// this platform once the footprint is large, and the ingest allocates and frees tens of GB of temporaries several times
+// over (measured at 2e9 entries: 3.1 s of hipMalloc for 64 GB in the CSR build alone).  Freed blocks of >= 64 MB are kept
+// and handed out again to requests they fit without much waste; dev_cache_trim() returns them to the driver.
+hipError_t dev_cache_malloc(void **p, size_t bytes);
+void dev_cache_free(void *p);
+void dev_cache_trim();
+
 template <typename T>
 static inline cellector_status dev_alloc(cellector_ctx *c, T **p, uint64_t n)
 {
     void *q = nullptr;
-    hipError_t e = hipMalloc(&q, (n ? n : 1) * sizeof(T));
+    hipError_t e = dev_cache_malloc(&q, (n ? n : 1) * sizeof(T));
     if (e != hipSuccess)
         return ctx_fail(c, CELLECTOR_ENOMEM, "hipMalloc(%llu bytes) failed: %s",
                         (unsigned long long)(n * sizeof(T)), hipGetErrorString(e));
@@ -188,7 +196,7 @@ static inline cellector_status dev_alloc(cellector_ctx *c, T **p, uint64_t n)
 template <typename T>
 static inline void dev_free(T *&p)
 {
-    if (p) (void)hipFree(p);
+    if (p) dev_cache_free((void *)p);
     p = nullptr;
 }
 

@@ -10,6 +10,9 @@
 
 #include <rocprim/rocprim.hpp>
 
+#include <chrono>
+#include <cstdlib>
+
 #include "ctx.h"
 #include "device_math.h"
 
@@ -311,6 +314,15 @@ cellector_status ingest_pass1(cellector_ctx *c)
 cellector_status ingest_build(cellector_ctx *c, uint64_t min_alt, uint64_t min_ref)
 {
     const uint64_t TL = c->total_loci, n = c->coo_n, nloc = c->nloc;
+    const bool timing = getenv("CELLECTOR_TIMING") != nullptr;  // phase wall times on stderr
+    auto t_prev = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!timing) return;
+        (void)hipStreamSynchronize(c->stream);
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[timing]     %-22s %8.3f s\n", what, std::chrono::duration<double>(now - t_prev).count());
+        t_prev = now;
+    };
     // ---- filter + compaction map
     CHK(dev_alloc(c, &c->to_used, TL + 1));
     hipLaunchKernelGGL(k_used_flag, dim3(g1(TL + 1)), dim3(IB), 0, c->stream, TL, c->x_pass1, (double)min_ref,
@@ -347,6 +359,7 @@ cellector_status ingest_build(cellector_ctx *c, uint64_t min_alt, uint64_t min_r
         c->coo_sorted = true;
     }
 
+    lap("filter + compaction");
     // ---- counts and pointers
     uint64_t *loc_cnt = nullptr, *col_cnt = nullptr;
     CHK(dev_alloc(c, &c->csr_ptr, nloc + 1));
@@ -370,20 +383,25 @@ cellector_status ingest_build(cellector_ctx *c, uint64_t min_alt, uint64_t min_r
                         (unsigned long long)nnz_rows, (unsigned long long)nnz_cols);
     c->nnz = nnz_rows;
 
+    lap("counts + scans");
     // ---- CSC = filtered file order; CSR = stable sort of the same entries by cell
     uint32_t *key = nullptr, *key_o = nullptr;
     uint64_t *val = nullptr;
     CHK(dev_alloc(c, &c->csc_ent, c->nnz)); CHK(dev_alloc(c, &c->csr_ent, c->nnz));
     CHK(dev_alloc(c, &key, c->nnz)); CHK(dev_alloc(c, &key_o, c->nnz)); CHK(dev_alloc(c, &val, c->nnz));
+    lap("allocations");
     if (n)
         hipLaunchKernelGGL(k_fill, dim3(g1(n)), dim3(IB), 0, c->stream, n, c->coo_locus, c->coo_cell, c->coo_alt,
                            c->coo_ref, c->to_used, loc_cnt, c->csc_ptr, c->csc_ent, key, val);
     HIPCHK(c, hipGetLastError());
+    lap("CSC fill");
     int bits = 1;
     while (bits < 32 && (1ull << bits) < nloc) bits++;
     CHK(dev_sort_pairs_u32_u64(c, key, key_o, val, c->csr_ent, c->nnz, bits));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    lap("sort by cell");
     dev_free(key); dev_free(key_o); dev_free(val); dev_free(loc_cnt);
+    lap("frees");
     (void)col_cnt;
     if (!c->keep_coo) {
         dev_free(c->coo_locus); dev_free(c->coo_cell); dev_free(c->coo_alt); dev_free(c->coo_ref);

@@ -20,6 +20,7 @@
 #include <map>
 #include <numeric>
 #include <optional>
+#include <chrono>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -275,13 +276,23 @@ int main(int argc, char **argv)
         }
     }
 
+    // CELLECTOR_TIMING=1: phase wall times on stderr (not part of the reference's output)
+    const bool timing = getenv("CELLECTOR_TIMING") != nullptr;
+    auto t_prev = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        const auto now = std::chrono::steady_clock::now();
+        if (timing) fprintf(stderr, "[timing] %-24s %8.3f s\n", what, std::chrono::duration<double>(now - t_prev).count());
+        t_prev = now;
+    };
     // load_cell_data (load_data.rs:134-181) on the device
     Ctx g;
     if (cellector_create(&g.c, params.device) != CELLECTOR_OK)
         die(EXIT_PANIC, "cellector: no usable MI355X device " + std::to_string(params.device) + " (there is no CPU fallback)");
     if (const char *e = getenv("CELLECTOR_ENGINE")) g.ck(cellector_set_option(g.c, "engine", atoi(e)), "engine");
     g.ck(cellector_set_option(g.c, "keep_coo", params.vcf ? 1 : 0), "option");
+    lap("barcodes + device init");
     g.ck(cellector_load_mtx(g.c, params.alt_mtx.c_str(), params.ref_mtx.c_str(), params.min_alt, params.min_ref), "load_cell_data");
+    lap("load_mtx (text -> device)");
     cellector_dims_t dm;
     g.ck(cellector_dims(g.c, &dm), "dims");
     const uint64_t N = dm.total_cells, L = dm.loci_used;
@@ -373,11 +384,13 @@ int main(int argc, char **argv)
         if (!s.any_change) break;
     }
 
+    lap("EM loop + iteration files");
     // calculate_posteriors (main.rs:228-280)
     std::vector<double> posterior(N), doublet(N), ll_maj(N), ll_min(N);
     std::vector<uint8_t> excluded(N);
     g.ck(cellector_posteriors(g.c, posterior.data(), doublet.data(), ll_maj.data(), ll_min.data()), "calculate_posteriors");
     g.ck(cellector_excluded(g.c, excluded.data()), "excluded");
+    lap("posteriors");
 
     // output_final_vcf (main.rs:52-131)
     if (params.vcf) {

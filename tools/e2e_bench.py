@@ -83,16 +83,17 @@ def main():
     times = []
     for _ in range(2):  # second run: page cache and driver warm, like the oracle's files
         t0 = time.perf_counter()
-        r = subprocess.run(cmd, capture_output=True, text=True)
+        r = subprocess.run(cmd, capture_output=True, text=True, env=dict(os.environ, CELLECTOR_TIMING="1"))
         times.append(time.perf_counter() - t0)
         assert r.returncode == 0, r.stderr
+    phases = [ln.split("]", 1)[1].strip() for ln in r.stderr.splitlines() if ln.startswith("[timing]")]
     n_iter = sum(1 for ln in r.stdout.splitlines() if ln.startswith("detected "))
     out_bytes = sum(os.path.getsize(os.path.join(out_dir, f)) for f in os.listdir(out_dir))
     res = {"workload": f"{N} cells x {L} loci, density {args.density}: text .mtx pair + barcodes + VCF -> all TSVs + cellector.vcf",
            "entries": n_entries, "text_bytes": int(sum(os.path.getsize(p) for p in paths.values())),
            "inputs_written_s": t_write, "device_writer": bool(args.device_writer),
            "em_iterations": n_iter, "output_bytes": int(out_bytes),
-           "gpu_cli_wall_s": times[1], "gpu_cli_first_run_s": times[0]}
+           "gpu_cli_wall_s": times[1], "gpu_cli_first_run_s": times[0], "gpu_cli_phases": phases}
     if not args.no_oracle:
         from oracle import binding as ob
         ob.set_threads(args.cpu_threads)
