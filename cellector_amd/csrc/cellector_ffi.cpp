@@ -113,8 +113,8 @@ hipError_t dev_cache_malloc(void **p, size_t bytes)
         size_t best = (size_t)-1;
         for (size_t i = 0; i < g_cache_free.size(); i++) {
             const DevBlock &b = g_cache_free[i];
-            // fits, wastes at most a quarter, and is the tightest such block
-            if (b.device == dev && b.bytes >= bytes && b.bytes - bytes <= bytes / 4 &&
+            // fits, is at most twice the request, and is the tightest such block
+            if (b.device == dev && b.bytes >= bytes && b.bytes - bytes <= bytes &&
                 (best == (size_t)-1 || b.bytes < g_cache_free[best].bytes))
                 best = i;
         }

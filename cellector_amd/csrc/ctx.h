@@ -177,7 +177,7 @@ cellector_status ctx_fail(const cellector_ctx *c, cellector_status s, const char
 // Device memory goes through a small caching layer (cellector_ffi.cpp): mapping fresh VRAM costs ~30-50 ms per GB on
 // this platform once the footprint is large, and the ingest allocates and frees tens of GB of temporaries several times
 // over (measured at 2e9 entries: 3.1 s of hipMalloc for 64 GB in the CSR build alone).  Freed blocks of >= 64 MB are kept
-// and handed out again to requests they fit without much waste; dev_cache_trim() returns them to the driver.
+// and handed out again to requests of at least half their size; dev_cache_trim() returns them to the driver.
 hipError_t dev_cache_malloc(void **p, size_t bytes);
 void dev_cache_free(void *p);
 void dev_cache_trim();

@@ -429,6 +429,7 @@ int main(int argc, char **argv)
         fclose(f);
     }
 
+    lap("final tallies + cellector.vcf");
     // output_final_assignments (main.rs:133-174)
     std::map<std::string, std::map<std::string, uint64_t>> assignment_gt_counts;
     std::map<std::string, uint64_t> gt_counts;
@@ -454,6 +455,7 @@ int main(int argc, char **argv)
         }
         fclose(f);
     }
+    lap("assignments file");
     {   // pretty_print (main.rs:177-226); ties in the count sort are in hash order there, by name here
         std::vector<std::pair<std::string, uint64_t>> cv(gt_counts.begin(), gt_counts.end());
         std::stable_sort(cv.begin(), cv.end(), [](const auto &a, const auto &b) { return a.second > b.second; });
