@@ -2,7 +2,7 @@
 //
 // The host only brings bytes (mmap for plain files, zlib inflate for ".gz", multi-member) and reads the three header
 // lines; the data lines are tokenised and converted on the GPU:
-//   k_nl_count / k_nl_fill   line starts: every thread looks at 16 bytes, per-thread newline counts are scanned, the
+//   k_nl_count / k_nl_fill   line starts: every thread looks at 128 bytes, per-thread newline counts are scanned, the
 //                            positions are written in order;
 //   k_parse_lines            one thread per line: split_whitespace + parse::<usize>() of the tokens the reference reads
 //                            (load_data.rs:190-204): alt file tokens 0,1,2 (locus, cell, alt count), ref file token 2 only
@@ -48,12 +48,19 @@ __device__ __forceinline__ uint32_t newline_mask16(const uint8_t *__restrict__ t
     return m;
 }
 
+// (a thread takes NL_SEG bytes = 8 units of 16: the count array is 1/16 of the text instead of 1/2 — at 30 GB of text per
+// file that is 15 GB of VRAM less to map)
+#define NL_SEG 128
 __global__ __launch_bounds__(PB) void k_nl_count(const uint8_t *__restrict__ text, uint64_t n, uint64_t *__restrict__ cnt)
 {
     const uint64_t t = (uint64_t)blockIdx.x * PB + threadIdx.x;
-    const uint64_t base = t * 16;
+    const uint64_t base = t * NL_SEG;
     if (base >= n) return;
-    cnt[t] = __popc(newline_mask16(text, n, base));
+    uint32_t k = 0;
+#pragma unroll
+    for (int u = 0; u < NL_SEG / 16; u++)
+        if (base + 16 * u < n) k += __popc(newline_mask16(text, n, base + 16 * u));
+    cnt[t] = k;
 }
 
 // line_start[k] = byte after the k-th newline (line 0 starts at 0 and is written by the caller's memset)
@@ -61,14 +68,18 @@ __global__ __launch_bounds__(PB) void k_nl_fill(const uint8_t *__restrict__ text
                                                 const uint64_t *__restrict__ off, uint64_t *__restrict__ line_start)
 {
     const uint64_t t = (uint64_t)blockIdx.x * PB + threadIdx.x;
-    const uint64_t base = t * 16;
+    const uint64_t base = t * NL_SEG;
     if (base >= n) return;
-    uint32_t m = newline_mask16(text, n, base);
     uint64_t k = off[t];
-    while (m) {
-        const int b = __ffs((int)m) - 1;
-        m &= m - 1;
-        line_start[1 + k++] = base + b + 1;
+    for (int u = 0; u < NL_SEG / 16; u++) {
+        const uint64_t ub = base + 16 * u;
+        if (ub >= n) break;
+        uint32_t m = newline_mask16(text, n, ub);
+        while (m) {
+            const int b = __ffs((int)m) - 1;
+            m &= m - 1;
+            line_start[1 + k++] = ub + b + 1;
+        }
     }
 }
 
@@ -316,7 +327,7 @@ cellector_status split_lines(cellector_ctx *c, const FileBytes &fb, DevText *dt)
 {
     const bool unterminated = dt->n > 0 && fb.data[fb.size - 1] != '\n';
     const uint64_t n_scan = dt->n + (unterminated ? 1 : 0);  // include one padding '\n' as the terminator
-    const uint64_t nthreads = (n_scan + 15) / 16;
+    const uint64_t nthreads = (n_scan + NL_SEG - 1) / NL_SEG;
     uint64_t *cnt = nullptr;
     CHK(dev_alloc(c, &cnt, nthreads + 1));
     HIPCHK(c, hipMemsetAsync(cnt, 0, (nthreads + 1) * 8, c->stream));
