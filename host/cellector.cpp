@@ -22,6 +22,7 @@
 #include <optional>
 #include <chrono>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -46,6 +47,41 @@ std::string fmt(double v)
     return std::string(buf, r.ptr);
 }
 std::string fmt(uint64_t v) { return std::to_string(v); }
+// the same, appended to a row under construction
+void put(std::string &o, double v)
+{
+    if (std::isnan(v)) { o += "NaN"; return; }
+    if (std::isinf(v)) { o += v > 0 ? "inf" : "-inf"; return; }
+    char buf[400];
+    auto r = std::to_chars(buf, buf + sizeof buf, v, std::chars_format::fixed);
+    o.append(buf, r.ptr);
+}
+void put(std::string &o, uint64_t v)
+{
+    char buf[24];
+    auto r = std::to_chars(buf, buf + sizeof buf, v);
+    o.append(buf, r.ptr);
+}
+// Formats rows [0, n) with row(i, out) on several host threads (contiguous ranges) and writes them in order: at 1M cells
+// the reference-shaped fprintf loops were a visible part of the run once the scoring itself takes milliseconds.
+template <class F>
+void write_rows(FILE *f, uint64_t n, F row)
+{
+    unsigned nt = std::thread::hardware_concurrency();
+    if (nt > 16) nt = 16;
+    if (nt < 1 || n < 20000) nt = 1;
+    std::vector<std::string> buf(nt);
+    auto work = [&](unsigned t) {
+        const uint64_t b = n * t / nt, e = n * (t + 1) / nt;
+        buf[t].reserve((size_t)(e - b) * 96);
+        for (uint64_t i = b; i < e; i++) row(i, buf[t]);
+    };
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < nt; t++) th.emplace_back(work, t);
+    work(0);
+    for (auto &x : th) x.join();
+    for (unsigned t = 0; t < nt; t++) fwrite(buf[t].data(), 1, buf[t].size(), f);
+}
 
 // ---- reader (load_data.rs:240-251): ".gz" by extension, multi-member ------------------------------------------
 struct Lines {
@@ -198,14 +234,16 @@ double ln_gamma(double x)
 }
 double ln_factorial(uint64_t x)
 {
-    static double cache[171];
-    static bool ready = false;
-    if (!ready) {
-        cache[0] = 1.0;
-        for (int i = 1; i <= 170; i++) cache[i] = cache[i - 1] * (double)i;
-        ready = true;
-    }
-    return x <= 170 ? std::log(cache[x]) : ln_gamma((double)x + 1.0);
+    struct Cache {  // statrs FCACHE: running f64 product (built once; thread-safe initialisation)
+        double v[171];
+        Cache()
+        {
+            v[0] = 1.0;
+            for (int i = 1; i <= 170; i++) v[i] = v[i - 1] * (double)i;
+        }
+    };
+    static const Cache cache;
+    return x <= 170 ? std::log(cache.v[x]) : ln_gamma((double)x + 1.0);
 }
 double binomial_pmf(double p, uint64_t n, uint64_t k)
 {
@@ -352,30 +390,32 @@ int main(int argc, char **argv)
                     printf("filtering locus %llu locus index %llu because it was contributing %s vs median %s per cell to "
                            "log likelihood of minority cells\n", (unsigned long long)locus_ids[l], (unsigned long long)l,
                            fmt(pc_min[l]).c_str(), fmt(med).c_str());
-            for (size_t l : order) {
-                const char *chrom = "na", *pos = "na";
-                if (params.vcf) {
+            if (params.vcf)
+                for (uint64_t l = 0; l < L; l++)
                     if (locus_ids[l] >= vcf_data.size()) die(EXIT_PANIC, "index out of bounds: vcf has fewer records than loci");
-                    chrom = vcf_data[locus_ids[l]].chrom.c_str();
-                    pos = vcf_data[locus_ids[l]].pos.c_str();
-                }
+            write_rows(f, L, [&](uint64_t i, std::string &o) {
+                const size_t l = order[i];
                 const double af_min = a_min[l] + r_min[l] ? (double)a_min[l] / (double)(a_min[l] + r_min[l]) : 0.0;
                 const double af_maj = a_maj[l] + r_maj[l] ? (double)a_maj[l] / (double)(a_maj[l] + r_maj[l]) : 0.0;
-                fprintf(f, "%llu\t%s\t%s\t%s\t%s\t%s\t%s\t%llu\t%llu\t%s\t%s\t%llu\t%llu\t%llu\t%llu\t%s\t%s\n",
-                        (unsigned long long)locus_ids[l], chrom, pos, fmt(c_min[l]).c_str(), fmt(c_maj[l]).c_str(),
-                        fmt(c_min[l]).c_str(), fmt(c_maj[l]).c_str(),  // quirk Q6: "expected" == plain contribution
-                        (unsigned long long)n_min[l], (unsigned long long)n_maj[l], fmt(pc_min[l]).c_str(),
-                        fmt(pc_maj[l]).c_str(), (unsigned long long)a_min[l], (unsigned long long)r_min[l],
-                        (unsigned long long)a_maj[l], (unsigned long long)r_maj[l], fmt(af_min).c_str(), fmt(af_maj).c_str());
-            }
+                put(o, locus_ids[l]); o += '\t';
+                if (params.vcf) { o += vcf_data[locus_ids[l]].chrom; o += '\t'; o += vcf_data[locus_ids[l]].pos; }
+                else o += "na\tna";
+                o += '\t'; put(o, c_min[l]); o += '\t'; put(o, c_maj[l]);
+                o += '\t'; put(o, c_min[l]); o += '\t'; put(o, c_maj[l]);  // quirk Q6: "expected" == plain contribution
+                o += '\t'; put(o, n_min[l]); o += '\t'; put(o, n_maj[l]);
+                o += '\t'; put(o, pc_min[l]); o += '\t'; put(o, pc_maj[l]);
+                o += '\t'; put(o, a_min[l]); o += '\t'; put(o, r_min[l]); o += '\t'; put(o, a_maj[l]); o += '\t'; put(o, r_maj[l]);
+                o += '\t'; put(o, af_min); o += '\t'; put(o, af_maj); o += '\n';
+            });
             fclose(f);
         }
         {   // output_iteration_tsv (main.rs:349-366)
             FILE *f = create(od + "/iteration_" + std::to_string(iteration) + ".tsv");
             fputs("cell_id\tbarcode\tassignment\tlog_likelihood\texpected_log_likelihood\tnum_loci_used\n", f);
-            for (uint64_t c = 0; c < N; c++)
-                fprintf(f, "%llu\t%s\t%s\t%s\t%s\t%s\n", (unsigned long long)c, barcodes[c].c_str(), ground_truth[c].c_str(),
-                        fmt(ll[c]).c_str(), fmt(ell[c]).c_str(), fmt(nloci[c]).c_str());
+            write_rows(f, N, [&](uint64_t c, std::string &o) {
+                put(o, c); o += '\t'; o += barcodes[c]; o += '\t'; o += ground_truth[c];
+                o += '\t'; put(o, ll[c]); o += '\t'; put(o, ell[c]); o += '\t'; put(o, nloci[c]); o += '\n';
+            });
             fclose(f);
             f = create(od + "/iteration_" + std::to_string(iteration) + "_threshold.tsv");
             fputs(fmt(s.threshold).c_str(), f);
@@ -402,18 +442,33 @@ int main(int argc, char **argv)
         std::string line;
         uint64_t rec = 0;
         const double ambient = 0.03, gt_thr = 0.99;
+        // the lines first (kind: 0 = "##" line, 1 = "#CHROM" line, 2 = record with its index), then formatted in parallel
+        std::vector<std::string> lines;
+        std::vector<uint64_t> rec_of;
         while (in.next(line)) {
-            if (line.rfind("##", 0) == 0) { fprintf(f, "%s\n", line.c_str()); continue; }
-            if (line.rfind("#CHROM", 0) == 0) { fprintf(f, "%s\tmajority\tminority\n", line.c_str()); continue; }
-            if (rec >= TL) die(EXIT_PANIC, "index out of bounds: vcf has more records than the matrix has loci");
-            const uint64_t tot_alt = amin[rec] + amaj[rec], tot_ref = rmin[rec] + rmaj[rec];
+            uint64_t kind = ~0ull;
+            if (line.rfind("##", 0) == 0) kind = ~0ull;
+            else if (line.rfind("#CHROM", 0) == 0) kind = ~0ull - 1;
+            else {
+                if (rec >= TL) die(EXIT_PANIC, "index out of bounds: vcf has more records than the matrix has loci");
+                kind = rec++;
+            }
+            lines.push_back(line);
+            rec_of.push_back(kind);
+        }
+        write_rows(f, lines.size(), [&](uint64_t i, std::string &o) {
+            const std::string &ln = lines[i];
+            if (rec_of[i] == ~0ull) { o += ln; o += '\n'; return; }
+            if (rec_of[i] == ~0ull - 1) { o += ln; o += "\tmajority\tminority\n"; return; }
+            const uint64_t r_ = rec_of[i];
+            const uint64_t tot_alt = amin[r_] + amaj[r_], tot_ref = rmin[r_] + rmaj[r_];
             const double soup = tot_alt + tot_ref > 0 ? (double)tot_alt / (double)(tot_alt + tot_ref) : 0.5;
             const double p_alt = (1.0 - ambient) * 0.99 + ambient * soup, p_het = (1.0 - ambient) * 0.5 + ambient * soup,
                          p_ref = (1.0 - ambient) * 0.01 + ambient * soup;
-            std::string gt[2];
+            const char *gt[2];
             double mx[2];
             for (int w = 0; w < 2; w++) {  // 0 = majority, 1 = minority
-                const uint64_t a = w ? amin[rec] : amaj[rec], r = w ? rmin[rec] : rmaj[rec];
+                const uint64_t a = w ? amin[r_] : amaj[r_], r = w ? rmin[r_] : rmaj[r_];
                 const double l_alt = binomial_pmf(p_alt, a + r, a), l_het = binomial_pmf(p_het, a + r, a),
                              l_ref = binomial_pmf(p_ref, a + r, a);
                 const double den = 1.0 / 3.0 * l_alt + 1.0 / 3.0 * l_het + 1.0 / 3.0 * l_ref;
@@ -421,11 +476,10 @@ int main(int argc, char **argv)
                 mx[w] = std::fmax(std::fmax(q_alt, q_het), q_ref);
                 gt[w] = q_alt > gt_thr ? "1/1" : q_het > gt_thr ? "0/1" : q_ref > gt_thr ? "0/0" : "./.";
             }
-            fprintf(f, "%s\tGT:GP:AO:RO\t%s:%s:%llu:%llu\t%s:%s:%llu:%llu\n", line.c_str(), gt[0].c_str(), fmt(mx[0]).c_str(),
-                    (unsigned long long)amaj[rec], (unsigned long long)rmaj[rec], gt[1].c_str(), fmt(mx[1]).c_str(),
-                    (unsigned long long)amin[rec], (unsigned long long)rmin[rec]);
-            rec++;
-        }
+            o += ln; o += "\tGT:GP:AO:RO\t";
+            o += gt[0]; o += ':'; put(o, mx[0]); o += ':'; put(o, amaj[r_]); o += ':'; put(o, rmaj[r_]); o += '\t';
+            o += gt[1]; o += ':'; put(o, mx[1]); o += ':'; put(o, amin[r_]); o += ':'; put(o, rmin[r_]); o += '\n';
+        });
         fclose(f);
     }
 
@@ -437,22 +491,26 @@ int main(int argc, char **argv)
         FILE *f = create(od + "/cellector_assignments.tsv");
         fputs("barcode\tposterior_assignment\tanomally_assignment\tlog_likelihood_loci_normalized\tloci_used\t"
               "posterior_assign_qual\tmajority_log_likelihood\tminority_log_likelihood\tground_truth_assignment\n", f);
+        static const char *const PA[4] = {"unassigned", "0", "1", "doublet"};
+        std::vector<uint8_t> pa_of(N);
         for (uint64_t c = 0; c < N; c++) {
-            const char *pa = "unassigned";
-            if (posterior[c] > params.posterior_threshold) pa = "0";
-            else if (1.0 - posterior[c] > params.posterior_threshold) pa = "1";
-            if (doublet[c] > 0.5) pa = "doublet";
-            if (entries_per_cell[c] < params.min_loci_used) pa = "unassigned";  // quirk Q5
-            assignment_gt_counts[pa][ground_truth[c]]++;
+            int pa = 0;
+            if (posterior[c] > params.posterior_threshold) pa = 1;
+            else if (1.0 - posterior[c] > params.posterior_threshold) pa = 2;
+            if (doublet[c] > 0.5) pa = 3;
+            if (entries_per_cell[c] < params.min_loci_used) pa = 0;  // quirk Q5
+            pa_of[c] = (uint8_t)pa;
+            assignment_gt_counts[PA[pa]][ground_truth[c]]++;
             gt_counts[ground_truth[c]]++;
-            const char *aa = excluded[c] ? "0" : "1";
+        }
+        write_rows(f, N, [&](uint64_t c, std::string &o) {
             const double post = std::fmax(posterior[c], 1.0 - posterior[c]);
             double q = std::fmin(-10.0 * std::log10(1.0 - post), 255.0);  // f64::min ignores NaN
             const uint64_t qual = (q != q || q < 0.0) ? 0 : (uint64_t)q;    // `as usize` saturates
-            fprintf(f, "%s\t%s\t%s\t%s\t%llu\t%llu\t%s\t%s\t%s\n", barcodes[c].c_str(), pa, aa, fmt(norm[c]).c_str(),
-                    (unsigned long long)nloci[c], (unsigned long long)qual, fmt(ll_maj[c]).c_str(), fmt(ll_min[c]).c_str(),
-                    ground_truth[c].c_str());
-        }
+            o += barcodes[c]; o += '\t'; o += PA[pa_of[c]]; o += '\t'; o += excluded[c] ? "0" : "1";
+            o += '\t'; put(o, norm[c]); o += '\t'; put(o, (uint64_t)nloci[c]); o += '\t'; put(o, qual);
+            o += '\t'; put(o, ll_maj[c]); o += '\t'; put(o, ll_min[c]); o += '\t'; o += ground_truth[c]; o += '\n';
+        });
         fclose(f);
     }
     lap("assignments file");
