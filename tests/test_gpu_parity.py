@@ -220,6 +220,32 @@ def test_overflow_side_stream_equals_in_stream(mods):
             assert np.array_equal(post_a[k], post_b[k]), k
 
 
+def test_device_text_writer_round_trip(mods, tmp_path):
+    """cellector_write_staged_mtx (benchmark utility): the text pair it formats on the device loads back — through the
+    device tokeniser and through the oracle's loader — as the very matrix it was written from."""
+    if mods["engine"] != 2:
+        pytest.skip("one engine is enough")
+    L, N = 900, 40000  # several generator tiles; line lengths from 6 to 13 bytes
+    g = mods["Cellector"](0)
+    g.set_option("keep_coo", 1)
+    g.ingest_synthetic(L, N, 0.02, seed=9)
+    alt, ref = str(tmp_path / "alt.mtx"), str(tmp_path / "ref.mtx")
+    g.write_staged_mtx(alt, ref)
+    g.ingest_finish(4, 4)
+    head = open(alt).read(200).splitlines()[:3]
+    assert head[0] == "%%MatrixMarket matrix coordinate real general" and head[2].split()[:2] == [str(L), str(N)]
+    h = mods["Cellector"](0)
+    h.load_mtx(alt, ref, 4, 4)
+    o = mods["ob"].Oracle.from_mtx(alt, ref, 4, 4)
+    _check_matrix(h, o)
+    dg, dh = g.dims(), h.dims()
+    assert (dg.loci_used, dg.nnz_used) == (dh.loci_used, dh.nnz_used)
+    rg, eg = g.csr_rows(0, N)
+    rh, eh = h.csr_rows(0, N)
+    assert np.array_equal(rg, rh) and np.array_equal(eg, eh)
+    g.close(); h.close(); o.close()
+
+
 def test_ll_pass_under_caller_alpha_beta_and_mask(mods):
     g, o, _ = _case(mods, 1500, 800, 0.1, seed=3)
     rng = np.random.default_rng(0)
