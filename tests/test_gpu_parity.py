@@ -72,8 +72,9 @@ def _check_iteration(g, o, sg, so):
     lg, lo_ = g.locus_outputs(), o.locus_outputs()
     for k in ("cells_min", "cells_maj", "alt_min", "ref_min", "alt_maj", "ref_maj"):
         assert np.array_equal(lg[k], lo_[k]), k
-    np.testing.assert_allclose(lg["contrib_min"], lo_["contrib_min"], rtol=0, atol=LL_ATOL)
-    np.testing.assert_allclose(lg["contrib_maj"], lo_["contrib_maj"], rtol=0, atol=1e-6)
+    # (sums over up to all cells of a locus: the oracle's own ln_gamma-difference error — ~1e-10 per entry at alpha+beta ~ 1e5, one-signed — grows with the sum: rtol)
+    np.testing.assert_allclose(lg["contrib_min"], lo_["contrib_min"], rtol=1e-8, atol=LL_ATOL)
+    np.testing.assert_allclose(lg["contrib_maj"], lo_["contrib_maj"], rtol=1e-8, atol=1e-6)
     assert np.array_equal(g.loci_mask(), o.loci_mask())
     assert sg.n_loci_filtered == so.n_loci_filtered
     ag, bg = g.alpha_betas()
