@@ -2,9 +2,8 @@
 //
 // The host only brings bytes (mmap for plain files, zlib inflate for ".gz", multi-member) and reads the three header
 // lines; the data lines are tokenised and converted on the GPU:
-//   k_nl_count / k_nl_fill   line starts: every thread looks at 128 bytes, per-thread newline counts are scanned, the
-//                            positions are written in order;
-//   k_parse_lines            one thread per line: split_whitespace + parse::<usize>() of the tokens the reference reads
+//   k_nl_count               newlines per 128-byte segment, scanned: the index of the first line that starts in a segment;
+//   k_parse_lines            a thread per segment, for every line that starts there: split_whitespace + parse::<usize>() of the tokens the reference reads
 //                            (load_data.rs:190-204): alt file tokens 0,1,2 (locus, cell, alt count), ref file token 2 only
 //                            (its indices are never read); any failure records the smallest offending line;
 //   k_pair_check / k_pair_fill   zip the two files (shorter one wins, like izip!), range checks, this shard's cell range,
@@ -63,35 +62,17 @@ __global__ __launch_bounds__(PB) void k_nl_count(const uint8_t *__restrict__ tex
     cnt[t] = k;
 }
 
-// line_start[k] = byte after the k-th newline (line 0 starts at 0 and is written by the caller's memset)
-__global__ __launch_bounds__(PB) void k_nl_fill(const uint8_t *__restrict__ text, uint64_t n,
-                                                const uint64_t *__restrict__ off, uint64_t *__restrict__ line_start)
-{
-    const uint64_t t = (uint64_t)blockIdx.x * PB + threadIdx.x;
-    const uint64_t base = t * NL_SEG;
-    if (base >= n) return;
-    uint64_t k = off[t];
-    for (int u = 0; u < NL_SEG / 16; u++) {
-        const uint64_t ub = base + 16 * u;
-        if (ub >= n) break;
-        uint32_t m = newline_mask16(text, n, ub);
-        while (m) {
-            const int b = __ffs((int)m) - 1;
-            m &= m - 1;
-            line_start[1 + k++] = ub + b + 1;
-        }
-    }
-}
-
 // ---- tokens ---------------------------------------------------------------------------------------------------
 // parse token `idx` of [p, e) as an unsigned integer (optional leading '+'); false on missing / malformed / > 2^32-1
+// parse tokens first_idx .. first_idx + n_tok - 1 of the LINE that starts at p (it ends at the next '\n'; e bounds the text)
+// as unsigned integers (optional leading '+'); false on a missing / malformed token or a value above 2^32-1
 __device__ bool token_u32(const uint8_t *__restrict__ p, const uint8_t *__restrict__ e, int first_idx, int n_tok,
                           uint32_t *out)
 {
     int t = 0;
     while (true) {
-        while (p < e && is_ws(*p)) p++;
-        if (p >= e) return false;
+        while (p < e && *p != '\n' && is_ws(*p)) p++;
+        if (p >= e || *p == '\n') return false;
         const uint8_t *s = p;
         while (p < e && !is_ws(*p)) p++;
         if (t >= first_idx) {
@@ -110,24 +91,58 @@ __device__ bool token_u32(const uint8_t *__restrict__ p, const uint8_t *__restri
     }
 }
 
-// ALT file: tokens 0,1,2 -> (locus1, cell1, count); REF file: token 2 -> count
+// ALT file: tokens 0,1,2 -> (locus1, cell1, count); REF file: token 2 -> count.  A thread takes the lines that START in its
+// NL_SEG bytes (line 0 at byte 0, line k after the k-th newline; off[t] = newlines before the segment, from the scan of
+// k_nl_count) — no array of line starts is ever materialised (at 2e9 lines per file that array was 16 GB of VRAM each).
+#define PARSE_TAIL 64  // bytes staged beyond the block's segments: a line that starts near the end finishes in there
 template <bool ALT>
 __global__ __launch_bounds__(PB) void k_parse_lines(const uint8_t *__restrict__ text, uint64_t n, uint64_t n_lines,
-                                                    const uint64_t *__restrict__ line_start, uint32_t *__restrict__ o0,
+                                                    const uint64_t *__restrict__ off, uint32_t *__restrict__ o0,
                                                     uint32_t *__restrict__ o1, uint32_t *__restrict__ o2,
                                                     unsigned long long *__restrict__ first_bad)
 {
-    const uint64_t i = (uint64_t)blockIdx.x * PB + threadIdx.x;
-    if (i >= n_lines) return;
-    const uint8_t *p = text + line_start[i];
-    const uint8_t *e = text + (i + 1 < n_lines ? line_start[i + 1] : n);
-    uint32_t v[3] = {0, 0, 0};
-    const bool ok = ALT ? token_u32(p, e, 0, 3, v) : token_u32(p, e, 2, 1, v);
-    if (!ok) {
-        atomicMin(first_bad, (unsigned long long)i);
-        return;
+    // the block's PB segments (+ a tail) go through LDS: coalesced 16-byte loads instead of byte-wise global reads
+    __shared__ __attribute__((aligned(16))) uint8_t s_text[PB * NL_SEG + PARSE_TAIL];
+    const uint64_t blk = (uint64_t)blockIdx.x * PB * NL_SEG;
+    const uint64_t avail = blk < n ? min((uint64_t)(PB * NL_SEG + PARSE_TAIL), n - blk) : 0;  // text has 16 bytes of padding
+    for (uint32_t i = threadIdx.x * 16; i < avail; i += PB * 16)
+        *reinterpret_cast<uint4 *>(s_text + i) = *reinterpret_cast<const uint4 *>(text + blk + i);
+    __syncthreads();
+    const uint64_t t = (uint64_t)blockIdx.x * PB + threadIdx.x;
+    const uint64_t base = t * NL_SEG;
+    if (base >= n) return;
+    auto line = [&](uint64_t i, uint64_t start) {
+        if (i >= n_lines || start >= n) return;
+        uint32_t v[3] = {0, 0, 0};
+        // inside the staged window (a line is far shorter than the tail) parse from LDS, else from the text itself
+        const uint64_t rel = start - blk;
+        const uint8_t *p = text + start, *e = text + n;
+        if (rel + PARSE_TAIL <= avail) {
+            const uint8_t *q = s_text + rel, *qe = q + PARSE_TAIL;
+            bool closed = false;
+            for (const uint8_t *z = q; z < qe; z++)
+                if (*z == '\n') { closed = true; break; }
+            if (closed) { p = q; e = qe; }
+        }
+        const bool ok = ALT ? token_u32(p, e, 0, 3, v) : token_u32(p, e, 2, 1, v);
+        if (!ok) {
+            atomicMin(first_bad, (unsigned long long)i);
+            return;
+        }
+        if (ALT) { o0[i] = v[0]; o1[i] = v[1]; o2[i] = v[2]; } else o2[i] = v[0];
+    };
+    if (t == 0) line(0, 0);
+    uint64_t k = off[t];
+    for (int u = 0; u < NL_SEG / 16; u++) {
+        const uint64_t ub = base + 16 * u;
+        if (ub >= n) break;
+        uint32_t m = newline_mask16(text, n, ub);
+        while (m) {
+            const int b = __ffs((int)m) - 1;
+            m &= m - 1;
+            line(++k, ub + b + 1);
+        }
     }
-    if (ALT) { o0[i] = v[0]; o1[i] = v[1]; o2[i] = v[2]; } else o2[i] = v[0];
 }
 
 // ---- zip, validate, shard filter ------------------------------------------------------------------------------
@@ -266,7 +281,8 @@ bool host_tok_u64(const std::string &s, int idx, uint64_t *out)
 struct DevText {
     uint8_t *text = nullptr;
     uint64_t n = 0, n_lines = 0;
-    uint64_t *line_start = nullptr;
+    uint64_t *seg_off = nullptr;  // newlines before each NL_SEG-byte segment (exclusive scan of k_nl_count)
+    uint64_t n_seg = 0;
 };
 
 inline unsigned pgrid(uint64_t n) { return (unsigned)((n + PB - 1) / PB ? (n + PB - 1) / PB : 1); }
@@ -328,20 +344,14 @@ cellector_status split_lines(cellector_ctx *c, const FileBytes &fb, DevText *dt)
     const bool unterminated = dt->n > 0 && fb.data[fb.size - 1] != '\n';
     const uint64_t n_scan = dt->n + (unterminated ? 1 : 0);  // include one padding '\n' as the terminator
     const uint64_t nthreads = (n_scan + NL_SEG - 1) / NL_SEG;
-    uint64_t *cnt = nullptr;
-    CHK(dev_alloc(c, &cnt, nthreads + 1));
-    HIPCHK(c, hipMemsetAsync(cnt, 0, (nthreads + 1) * 8, c->stream));
-    if (nthreads) hipLaunchKernelGGL(k_nl_count, dim3(pgrid(nthreads)), dim3(PB), 0, c->stream, dt->text, n_scan, cnt);
+    CHK(dev_alloc(c, &dt->seg_off, nthreads + 1));
+    HIPCHK(c, hipMemsetAsync(dt->seg_off, 0, (nthreads + 1) * 8, c->stream));
+    if (nthreads) hipLaunchKernelGGL(k_nl_count, dim3(pgrid(nthreads)), dim3(PB), 0, c->stream, dt->text, n_scan, dt->seg_off);
     HIPCHK(c, hipGetLastError());
     uint64_t n_nl = 0;
-    CHK(dev_exclusive_scan_u64(c, cnt, nthreads + 1, &n_nl));
+    CHK(dev_exclusive_scan_u64(c, dt->seg_off, nthreads + 1, &n_nl));
     dt->n_lines = n_nl;  // every line is terminated now
-    CHK(dev_alloc(c, &dt->line_start, n_nl + 1));
-    HIPCHK(c, hipMemsetAsync(dt->line_start, 0, 8, c->stream));
-    if (nthreads) hipLaunchKernelGGL(k_nl_fill, dim3(pgrid(nthreads)), dim3(PB), 0, c->stream, dt->text, n_scan, cnt, dt->line_start);
-    HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    dev_free(cnt);
+    dt->n_seg = nthreads;
     dt->n = n_scan;
     return CELLECTOR_OK;
 }
@@ -416,7 +426,7 @@ cellector_status ingest_stage_mtx_device(cellector_ctx *c, MtxInput *in)
     unsigned long long *bad = nullptr;
     uint64_t *keep = nullptr;
     auto cleanup = [&]() {
-        dev_free(ta.text); dev_free(ta.line_start); dev_free(tr.text); dev_free(tr.line_start);
+        dev_free(ta.text); dev_free(ta.seg_off); dev_free(tr.text); dev_free(tr.seg_off);
         dev_free(l1); dev_free(c1); dev_free(a); dev_free(r); dev_free(flags); dev_free(bad); dev_free(keep);
     };
 #define PCHK(expr)                     \
@@ -438,9 +448,9 @@ cellector_status ingest_stage_mtx_device(cellector_ctx *c, MtxInput *in)
     if (e == hipSuccess) e = hipMemcpy(flags, h_flags, sizeof h_flags, hipMemcpyHostToDevice);
     if (e != hipSuccess) { cleanup(); return ctx_fail(c, CELLECTOR_EDEVICE, "parse: %s", hipGetErrorString(e)); }
     if (n) {
-        hipLaunchKernelGGL(k_parse_lines<true>, dim3(pgrid(n)), dim3(PB), 0, c->stream, ta.text, ta.n, n, ta.line_start, l1, c1,
+        hipLaunchKernelGGL(k_parse_lines<true>, dim3(pgrid(ta.n_seg)), dim3(PB), 0, c->stream, ta.text, ta.n, n, ta.seg_off, l1, c1,
                            a, bad);
-        hipLaunchKernelGGL(k_parse_lines<false>, dim3(pgrid(n)), dim3(PB), 0, c->stream, tr.text, tr.n, n, tr.line_start,
+        hipLaunchKernelGGL(k_parse_lines<false>, dim3(pgrid(tr.n_seg)), dim3(PB), 0, c->stream, tr.text, tr.n, n, tr.seg_off,
                            (uint32_t *)nullptr, (uint32_t *)nullptr, r, bad);
     }
     e = hipMemcpy(h_bad, bad, sizeof h_bad, hipMemcpyDeviceToHost);
@@ -451,7 +461,7 @@ cellector_status ingest_stage_mtx_device(cellector_ctx *c, MtxInput *in)
     }
     // the text and the line starts are done with: hand their blocks back before the next arrays are allocated, so that the
     // allocation cache can reuse them (every GB of fresh VRAM costs 30-50 ms)
-    dev_free(ta.text); dev_free(ta.line_start); dev_free(tr.text); dev_free(tr.line_start);
+    dev_free(ta.text); dev_free(ta.seg_off); dev_free(tr.text); dev_free(tr.seg_off);
     PCHK(dev_alloc(c, &keep, n + 1));
     hipLaunchKernelGGL(k_pair_check, dim3(pgrid(n + 1)), dim3(PB), 0, c->stream, n, l1, c1, a, r, c->total_loci, c->total_cells,
                        c->cell_begin, c->cell_end, keep, bad + 1, flags, flags + 1);
