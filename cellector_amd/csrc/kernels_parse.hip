@@ -292,6 +292,7 @@ inline unsigned pgrid(uint64_t n) { return (unsigned)((n + PB - 1) / PB ? (n + P
 // threads copy each piece into one of two pinned buffers while the previous piece is on its way over PCIe.
 #define UP_PIECE (256ull << 20)
 #define UP_THREADS 8
+#define UP_MIN (4ull << 30)
 cellector_status upload_text(cellector_ctx *c, const FileBytes &fb, size_t data_off, DevText *dt)
 {
     HIPCHK(c, hipSetDevice(c->device));
@@ -299,8 +300,10 @@ cellector_status upload_text(cellector_ctx *c, const FileBytes &fb, size_t data_
     // a final line without '\n' still counts (BufRead::lines); normalise by treating the end of data as a terminator
     CHK(dev_alloc(c, &dt->text, dt->n + 16));
     HIPCHK(c, hipMemset(dt->text + dt->n, '\n', 16));
-    if (dt->n < UP_PIECE) {  // small file: not worth the pinned buffers
-        if (dt->n) HIPCHK(c, hipMemcpy(dt->text, fb.data + data_off, dt->n, hipMemcpyHostToDevice));
+    if (dt->n < UP_MIN) {  // pinning the two buffers costs ~0.1 s: only worth it for multi-GB files
+        const size_t piece = 1ull << 30;
+        for (size_t o = 0; o < dt->n; o += piece)
+            HIPCHK(c, hipMemcpy(dt->text + o, fb.data + data_off + o, std::min(piece, (size_t)dt->n - o), hipMemcpyHostToDevice));
         return CELLECTOR_OK;
     }
     uint8_t *pin[2] = {nullptr, nullptr};
