@@ -204,7 +204,8 @@ cellector_status cellector_create(cellector_ctx **out, int device_id)
               create_side_stream(&c->side) &&
               hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) == hipSuccess &&
               hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) == hipSuccess &&
-              hipEventCreateWithFlags(&c->ev_join2, hipEventDisableTiming) == hipSuccess;
+              hipEventCreateWithFlags(&c->ev_join2, hipEventDisableTiming) == hipSuccess &&
+              hipEventCreateWithFlags(&c->ev_sum, hipEventDisableTiming) == hipSuccess;
     if (!ok) {
         cellector_destroy(c);
         return CELLECTOR_EDEVICE;
@@ -226,6 +227,7 @@ void cellector_destroy(cellector_ctx *c)
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->ev_join2) (void)hipEventDestroy(c->ev_join2);
+    if (c->ev_sum) (void)hipEventDestroy(c->ev_sum);
     delete c;
     dev_cache_trim();
 }
@@ -515,6 +517,7 @@ cellector_status cellector_bind_exchange_buffer(cellector_ctx *c, cellector_xchg
 {
     if (!c || !dev_ptr) return CELLECTOR_EINVAL;
     double *p = (double *)dev_ptr;
+    c->tables_prebuilt = false;  // (tables built ahead read the old buffers)
     switch (which) {
     case CELLECTOR_XCHG_PASS1:
         REQUIRE(c, c->state == cellector_ctx::ST_EMPTY, "bind PASS1 before ingest");
@@ -551,6 +554,7 @@ cellector_status cellector_em_begin(cellector_ctx *c)
     REQUIRE(c, c->em_phase == 0, "em_begin: previous iteration not finished");
     SETDEV(c);
     // engine 2 forms alpha/beta inside its first kernel (k_build_tables); an empty shard has no cell pass at all
+    if (c->engine != 2 || c->prebuilt_expected != c->compute_expected) c->tables_prebuilt = false;
     if (c->engine != 2 || c->nloc == 0) CHK(launch_alpha_beta(c));
     if (c->nloc != c->total_cells)  // other shards' slices must be zero before the sum-exchange
         HIPCHK(c, hipMemsetAsync(c->x_norm, 0, c->total_cells * 8, c->stream));
@@ -588,7 +592,11 @@ cellector_status cellector_em_finish(cellector_ctx *c, cellector_iter_summary *o
     SETDEV(c);
     CHK(launch_locus_filter(c));
     CHK(launch_iter_summary(c));
-    HIPCHK(c, hipStreamSynchronize(c->stream));  // the iteration's only host synchronisation
+    HIPCHK(c, hipEventRecord(c->ev_sum, c->stream));
+    // the next iteration's first kernel is queued behind the summary: it runs while the host waits for the summary, wakes
+    // up and decides (should the loop end here, the tables it built are simply never used)
+    if (c->engine == 2 && c->tiled_ready) CHK(tiled_prebuild_tables(c));
+    HIPCHK(c, hipEventSynchronize(c->ev_sum));  // the iteration's only host synchronisation
     double cnt[LC_COUNTERS];
     uint32_t dc[8] = {0};
     for (int i = 0; i < LC_COUNTERS; i++) cnt[i] = c->h_sel[i];
@@ -703,6 +711,8 @@ cellector_status cellector_cell_log_likelihoods(cellector_ctx *c, const double *
     REQUIRE(c, alpha && beta, "null alpha/beta");
     REQUIRE(c, c->em_phase == 0, "iteration in flight");
     SETDEV(c);
+    c->tables_prebuilt = false;  // this pass overwrites alpha/beta and the tables
+    c->work_zeroed = false;
     CHK(launch_ab_from_host(c, alpha, beta, mask));
     // the tiled engine derives the used-locus count from the ctx's own mask; with a caller mask use the CSR kernel
     if (c->engine == 2 && !mask && c->n_masked_loci == 0) CHK(tiled_cell_pass(c, c->ab, nullptr, false));

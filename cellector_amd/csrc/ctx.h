@@ -44,7 +44,7 @@ struct cellector_ctx {
     hipStream_t stream = nullptr;
     // side stream for the small overflow kernels that run next to the tile kernel (fork/join with events)
     hipStream_t side = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr, ev_sum = nullptr;
     int overlap = 1;  // option "overlap": 1 = the overflow kernels run on the side stream next to the tile kernel, 0 = in front
     mutable std::string err;
 
@@ -146,6 +146,8 @@ struct cellector_ctx {
     double *sel_out = nullptr;      // [16] device: [0..5] order statistics, [8..10] median, iqr, threshold
     double *h_sel = nullptr;        // pinned [32]: iteration summary written by k_iter_summary, read in em_finish
     double *h_sum_dev = nullptr;    // the device's address of h_sel
+    bool tables_prebuilt = false;   // the next iteration's k_build_tables is already queued / done (em_finish)
+    bool prebuilt_expected = false; // ... with this value of compute_expected
     bool work_zeroed = false;       // tile_work was reset by this iteration's k_alpha_beta
 
     // iteration bookkeeping
@@ -238,6 +240,7 @@ void tiled_free(cellector_ctx *c);
 cellector_status tiled_cell_pass(cellector_ctx *c, const double2 *ab, double *norm_out, bool for_em);
 cellector_status tiled_locus_pass(cellector_ctx *c);
 cellector_status tiled_masked_update(cellector_ctx *c);
+cellector_status tiled_prebuild_tables(cellector_ctx *c);
 cellector_status tiled_posteriors(cellector_ctx *c, double mf0, double lp_min, double lp_maj, double lp_dbl);
 // device-side mtx text parse (kernels_parse.hip)
 struct MtxInput;

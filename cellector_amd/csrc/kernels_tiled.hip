@@ -1583,7 +1583,8 @@ static cellector_status side_join(cellector_ctx *c)
 }
 
 // the chunk tables of one pass
-static cellector_status build_tile_tables(cellector_ctx *c, const double2 *ab, int set, bool expected, bool form_ab = false)
+static cellector_status build_tile_tables(cellector_ctx *c, const double2 *ab, int set, bool expected, bool form_ab = false,
+                                          const uint8_t *mask = nullptr)
 {
     const uint64_t tab_elems = (uint64_t)c->t_nj * TAB_ELEMS;
     double *tab = expected ? c->tab + 3 * tab_elems : c->tab + (uint64_t)set * tab_elems;
@@ -1593,7 +1594,7 @@ static cellector_status build_tile_tables(cellector_ctx *c, const double2 *ab, i
         const uint64_t L = c->L;
         src.s_alt = c->s_alt; src.s_ref = c->s_ref;
         src.alt_min = c->x_locus + LB_ALT_MIN * L; src.ref_min = c->x_locus + LB_REF_MIN * L;
-        src.mask = c->mask; src.ab_out = c->ab;
+        src.mask = mask ? mask : c->mask; src.ab_out = c->ab;
         src.xl_counters = c->x_locus + (uint64_t)LB_PLANES * L; src.d_counters = c->d_counters;
         src.tile_work = c->tile_work; src.n_work = 3u * T_GROUPS_MAX;
         c->work_zeroed = true;
@@ -1656,7 +1657,8 @@ cellector_status tiled_cell_pass(cellector_ctx *c, const double2 *ab, double *no
     // tile workgroups leave it is several times slower than alone, but it ends well inside the tile kernel's time.  In an
     // EM iteration the locus side's values follow on the side stream once the tile kernel is done; the locus finalize
     // waits for them (tiled_locus_pass).  (overlap 0: everything in the main stream.)
-    CHK(build_tile_tables(c, ab, 0, c->compute_expected, for_em));
+    if (for_em && c->tables_prebuilt) c->tables_prebuilt = false;  // built ahead by the previous iteration's em_finish
+    else CHK(build_tile_tables(c, ab, 0, c->compute_expected, for_em));
     if (ovf && c->overlap) {
         CHK(side_fork(c));
         launch_overflow_cell(c, c->side, ab, 0, c->compute_expected);
@@ -1763,6 +1765,18 @@ cellector_status tiled_locus_pass(cellector_ctx *c)
     return CELLECTOR_OK;
 }
 
+// The NEXT iteration's first kernel (alpha/beta + tables + counter reset), queued by em_finish behind the locus filter and
+// the summary kernel, i.e. before the host waits for the summary: it then runs while the host wakes up and decides.  It
+// reads what the next em_begin would read: the exchanged tallies and the filtered mask (mask_next, about to become mask).
+cellector_status tiled_prebuild_tables(cellector_ctx *c)
+{
+    if (c->nloc == 0 || c->L == 0) return CELLECTOR_OK;
+    CHK(build_tile_tables(c, c->ab, 0, c->compute_expected, true, c->mask_next));
+    c->tables_prebuilt = true;
+    c->prebuilt_expected = c->compute_expected;
+    return CELLECTOR_OK;
+}
+
 // called after the locus filter with mask = this iteration's mask, mask_next = filtered mask
 cellector_status tiled_masked_update(cellector_ctx *c)
 {
@@ -1779,6 +1793,8 @@ cellector_status tiled_masked_update(cellector_ctx *c)
 
 cellector_status tiled_posteriors(cellector_ctx *c, double mf0, double lp_min, double lp_maj, double lp_dbl)
 {
+    c->tables_prebuilt = false;  // the posterior passes rebuild table set 0 and use its column counters
+    c->work_zeroed = false;
     const uint64_t L = c->L;
     if (L)
         hipLaunchKernelGGL(k_ab_posterior3, dim3(gcap(L, 256)), dim3(256), 0, c->stream, L, c->s_alt, c->s_ref,
