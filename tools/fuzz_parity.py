@@ -95,7 +95,7 @@ def main():
 
 def run_two_shards(Cellector, ffi, o, L, N, lo, ce, al, re, min_alt, min_ref, opts):
     """two shard contexts driven through the exchange buffers on one GPU (host-summed), against the oracle"""
-    cut = N // 2
+    cut = int(np.random.default_rng(N * 7919 + L).choice([0, N // 3, N // 2, N]))  # an empty shard now and then
     gs = []
     for cb, cend in ((0, cut), (cut, N)):
         g = Cellector(0)
