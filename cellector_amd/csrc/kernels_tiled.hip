@@ -32,20 +32,23 @@
 
 #define T_K 4           // entries with 1 <= alt+ref <= T_K are "regular": log-pmf and expected term come from tables
 #define T_NCODE 14      // (alt, ref) combinations with 1 <= n <= T_K: K(K+3)/2
-#define T_ROWS 15       // table rows per chunk: the T_NCODE codes and one row of zeros for the padding entries
-#define T_BL 384        // loci per chunk: the paired table is T_ROWS * T_BL * 16 B = 90 KB of LDS
+#define T_LROW 18       // table doubles per locus: the T_NCODE log-pmfs, then the T_K expected terms
+#define T_BL 640        // locus slots per chunk (the table is T_BL * T_LROW * 8 B = 90 KB of LDS); the last slot is all zeros
+#define T_BLU (T_BL - 1)  // loci per chunk
 #define T_BC 1024       // cells per block == threads per workgroup
 #define T_THREADS 1024
 #define T_SB_MAX 4      // cell blocks per workgroup sharing one staged table (2 or 4: chosen per launch)
 #define T_GROUPS_MAX 64 // upper bound of the chunk groups of a launch
 #define T_GROUPS 8      // chunk groups (== XCDs: the workgroups of a group run on one XCD and share its L2)
 #define T_NE 15         // entries per cell of a slice held in registers (two 16-byte loads); longer slices: slow path
-#define T_NULL ((uint16_t)(T_NCODE * T_BL))  // padding entry: first element of the zero row
+// A u16 entry = n-1 << 14 | locus slot << 4 | code: log-pmf at table[slot * T_LROW + code], expected term at
+// table[slot * T_LROW + T_NCODE + (n-1)].
+#define T_NULL ((uint16_t)(T_BLU << 4))  // padding entry: code 0, n-1 = 0 of the zero slot
 // A slice in `tiles` is 64 rows of K+1 u16 (K odd): row i = [cell (0..1023) that lane i works for, K entries of that cell,
 // padded with T_NULL].  Tile header (fixed stride, in u16 units): 16 slices x {u64 first u16 of the slice in `tiles`,
 // u32 K, u32 pad}.
 #define T_HDR 128
-#define TAB_ELEMS ((uint64_t)T_ROWS * T_BL)  // table elements per chunk
+#define TAB_ELEMS ((uint64_t)T_LROW * T_BL)  // table doubles per chunk
 
 // code = n(n+1)/2 - 1 + ref:  n=1: (1,0)(0,1)  n=2: (2,0)(1,1)(0,2)  n=3: (3,0)..(0,3)  n=4: (4,0)..(0,4)
 __device__ __constant__ uint8_t T_A_OF[T_NCODE] = {1, 0, 2, 1, 0, 3, 2, 1, 0, 4, 3, 2, 1, 0};
@@ -87,10 +90,12 @@ __global__ void k_build_tables(uint64_t L, uint32_t nj, const double2 *__restric
         if (threadIdx.x < 8) src.d_counters[threadIdx.x] = 0u;
         for (uint32_t i = threadIdx.x; i < src.n_work; i += blockDim.x) src.tile_work[i] = 0u;
     }
-    const uint64_t l = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (l >= (uint64_t)nj * T_BL) return;
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;  // (chunk, slot)
+    if (t >= (uint64_t)nj * T_BL) return;
+    const uint64_t chunk = t / T_BL, slot = t % T_BL;
+    const uint64_t l = chunk * T_BLU + slot;
     double2 p = make_double2(-1.0, -1.0);
-    if (l < L) {
+    if (slot < T_BLU && l < L) {
         if (src.s_alt) {
             p.x = (src.s_alt[l] + 1.0) - src.alt_min[l];
             p.y = (src.s_ref[l] + 1.0) - src.ref_min[l];
@@ -101,17 +106,11 @@ __global__ void k_build_tables(uint64_t L, uint32_t nj, const double2 *__restric
         }
     }
     const bool live = p.x >= 0.0;
-    double ex[T_K + 1];
+    double *row = tab + chunk * TAB_ELEMS + slot * T_LROW;
 #pragma unroll
-    for (int n = 1; n <= T_K; n++) ex[n] = (PAIRS && live) ? dm_expected_log_pmf(lf, p.x, p.y, (uint32_t)n) : 0.0;
-    const uint64_t base = (l / T_BL) * TAB_ELEMS + (l % T_BL);
+    for (int w = 0; w < T_NCODE; w++) row[w] = live ? dm_log_bb_pmf(lf, p.x, p.y, T_A_OF[w], T_R_OF[w]) : 0.0;
 #pragma unroll
-    for (int w = 0; w < T_ROWS; w++) {
-        const double t = (live && w < T_NCODE) ? dm_log_bb_pmf(lf, p.x, p.y, T_A_OF[w % T_NCODE], T_R_OF[w % T_NCODE]) : 0.0;
-        const double e = w < T_NCODE ? ex[T_A_OF[w % T_NCODE] + T_R_OF[w % T_NCODE]] : 0.0;
-        if (PAIRS) reinterpret_cast<double2 *>(tab)[base + (uint64_t)w * T_BL] = make_double2(t, e);
-        else tab[base + (uint64_t)w * T_BL] = t;
-    }
+    for (int n = 1; n <= T_K; n++) row[T_NCODE + n - 1] = (PAIRS && live) ? dm_expected_log_pmf(lf, p.x, p.y, (uint32_t)n) : 0.0;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -143,11 +142,11 @@ __global__ __launch_bounds__(T_THREADS, 4) void k_tile_ll(uint32_t nb, uint32_t 
     // each tile.  Everything a step needs was requested two steps earlier: in every step the values loaded before are
     // consumed FIRST, then the next loads are issued as straight-line, unconditional instructions (indices are clamped
     // instead of guarded).
-    using tab_t = typename std::conditional<EXPECTED, double2, double>::type;
-    constexpr uint32_t TAB_U = T_ROWS * T_BL * sizeof(tab_t) / 16;  // 16-byte units per chunk table
-    constexpr int NP = (TAB_U + T_THREADS - 1) / T_THREADS;         // units per thread (the last one partial)
-    static_assert(NP == 6 || NP == 3, "table prefetch registers are written out by hand");
-    __shared__ tab_t s_tab[T_ROWS * T_BL];
+    using tab_t = typename std::conditional<EXPECTED, double2, double>::type;  // (log-pmf, expected) sums of a cell
+    constexpr uint32_t TAB_U = T_LROW * T_BL * sizeof(double) / 16;  // 16-byte units per chunk table
+    constexpr int NP = (TAB_U + T_THREADS - 1) / T_THREADS;          // units per thread (the last one partial)
+    static_assert(NP == 6, "table prefetch registers are written out by hand");
+    __shared__ __attribute__((aligned(16))) double s_tab[T_LROW * T_BL];
     __shared__ tab_t s_acc[T_SB * T_BC];  // per-cell sums of the workgroup's blocks
     __shared__ uint32_t s_col;
     const uint32_t tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
@@ -176,12 +175,10 @@ __global__ __launch_bounds__(T_THREADS, 4) void k_tile_ll(uint32_t nb, uint32_t 
         const double2 *src__ = reinterpret_cast<const double2 *>(tab) + (uint64_t)(J) * TAB_U + tid;             \
         p_t0 = src__[0];                                                                                         \
         p_t1 = src__[T_THREADS];                                                                                 \
-        p_t2 = src__[2 * T_THREADS]; /* NP == 3: partial, reads into the next chunk / the tail pad */            \
-        if constexpr (NP == 6) {                                                                                 \
-            p_t3 = src__[3 * T_THREADS];                                                                         \
-            p_t4 = src__[4 * T_THREADS];                                                                         \
-            p_t5 = src__[5 * T_THREADS]; /* partial */                                                           \
-        }                                                                                                        \
+        p_t2 = src__[2 * T_THREADS];                                                                             \
+        p_t3 = src__[3 * T_THREADS];                                                                             \
+        p_t4 = src__[4 * T_THREADS];                                                                             \
+        p_t5 = src__[5 * T_THREADS]; /* partial: reads into the next chunk / the tail pad */                     \
     } while (0)
 
     // Software pipeline over the steps t = (chunk, block) of this workgroup: the rows of step t+2 are requested in step
@@ -225,13 +222,18 @@ __global__ __launch_bounds__(T_THREADS, 4) void k_tile_ll(uint32_t nb, uint32_t 
     uint32_t t = 0;
 
     // one step: block S of the current chunk, pipeline buffers E / H
-#if TILE_ABL == 1  /* ablation: no table lookups */
-#define TILE_LOOKUP(V, IDX) do { if constexpr (EXPECTED) V = make_double2((double)(IDX), 1.0); else V = (double)(IDX); } while (0)
-#else
-#define TILE_LOOKUP(V, IDX) V = s_tab[IDX]
-#endif
     // lookup of entry KK of the row = u16 number KK + 1 = half (KK + 1) & 1 of dword (KK + 1) >> 1.  The slice's K is odd
     // and wave-uniform, so the lookups come in pairs behind one scalar branch.
+#if TILE_ABL == 1  /* ablation: no table lookups */
+#define TILE_LOOKUP(V, E16) do { if constexpr (EXPECTED) V = make_double2((double)(E16), 1.0); else V = (double)(E16); } while (0)
+#else
+#define TILE_LOOKUP(V, E16)                                                                                      \
+    do {                                                                                                         \
+        const uint32_t b__ = (((E16) >> 4) & 1023u) * T_LROW;                                                    \
+        if constexpr (EXPECTED) V = make_double2(s_tab[b__ + ((E16) & 15u)], s_tab[b__ + T_NCODE + ((E16) >> 14)]); \
+        else V = s_tab[b__ + ((E16) & 15u)];                                                                     \
+    } while (0)
+#endif
 #define TILE_RD(V, KK)                                                                                           \
     tab_t V;                                                                                                     \
     do {                                                                                                         \
@@ -278,7 +280,8 @@ __global__ __launch_bounds__(T_THREADS, 4) void k_tile_ll(uint32_t nb, uint32_t 
             TILE_LEVEL(13, 14, v11, v12,                                                                         \
                 TILE_ADD(v13); TILE_ADD(v14);                                                                    \
                 for (uint32_t k = T_NE; k < K__; k++) { /* rare: a slice with more than T_NE entries per cell */ \
-                    const tab_t v__ = s_tab[cur__[k + 1]];                                                       \
+                    tab_t v__;                                                                                   \
+                    TILE_LOOKUP(v__, (uint32_t)cur__[k + 1]);                                                    \
                     TILE_ADD(v__);                                                                               \
                 } ))))))                                                                                         \
         } else TILE_ADD(v0);                                                                                     \
@@ -300,14 +303,10 @@ __global__ __launch_bounds__(T_THREADS, 4) void k_tile_ll(uint32_t nb, uint32_t 
             double2 *dst = reinterpret_cast<double2 *>(s_tab) + tid;
             dst[0] = p_t0;
             dst[T_THREADS] = p_t1;
-            if constexpr (NP == 6) {
-                dst[2 * T_THREADS] = p_t2;
-                dst[3 * T_THREADS] = p_t3;
-                dst[4 * T_THREADS] = p_t4;
-                if (tid + 5 * T_THREADS < TAB_U) dst[5 * T_THREADS] = p_t5;
-            } else {
-                if (tid + 2 * T_THREADS < TAB_U) dst[2 * T_THREADS] = p_t2;
-            }
+            dst[2 * T_THREADS] = p_t2;
+            dst[3 * T_THREADS] = p_t3;
+            dst[4 * T_THREADS] = p_t4;
+            if (tid + 5 * T_THREADS < TAB_U) dst[5 * T_THREADS] = p_t5;
         }
 #if TILE_ABL != 3
         TABLE_PREFETCH(min(j + 1, j1 - 1));
@@ -1009,7 +1008,7 @@ __global__ __launch_bounds__(256) void k_locus_finalize(uint64_t L, int locus_mo
         for (int p = 0; p < nplanes; p++) cnt += hist_min[((uint64_t)p * L + l) * 16 + j];
         const uint32_t h_all = hist_all[l * T_NCODE + j];
         // (element stride 2 when the table holds (log-pmf, expected) pairs)
-        const double t_code = tab[((l / T_BL) * TAB_ELEMS + (uint64_t)j * T_BL + (l % T_BL)) * tab_stride];
+        const double t_code = tab[(l / T_BLU) * TAB_ELEMS + (l % T_BLU) * T_LROW + j];
         amin = (uint64_t)cnt * T_A_OF[j];
         rmin = (uint64_t)cnt * T_R_OF[j];
         if (live) {
@@ -1171,8 +1170,8 @@ __global__ __launch_bounds__(T_BC) void k_tile_build(uint64_t nloc, uint32_t nj,
     uint32_t len = 0;
     if (row < nloc) {
         const uint64_t beg = csr_ptr[row], end = csr_ptr[row + 1];
-        lo = row_lower_bound(csr_ent, beg, end, j * T_BL);
-        hi = row_lower_bound(csr_ent, lo, end, (j + 1u) * T_BL);
+        lo = row_lower_bound(csr_ent, beg, end, j * T_BLU);
+        hi = row_lower_bound(csr_ent, lo, end, (j + 1u) * T_BLU);
         for (uint64_t i = lo; i < hi; i++) len += ent_regular(csr_ent[i]) ? 1u : 0u;
     }
     __syncthreads();
@@ -1237,7 +1236,8 @@ __global__ __launch_bounds__(T_BC) void k_tile_build(uint64_t nloc, uint32_t nj,
     uint32_t k = 0;
     for (uint64_t i = lo; i < hi; i++) {
         const uint64_t e = csr_ent[i];
-        if (ent_regular(e)) dst[1 + k++] = (uint16_t)(ent_code(e) * T_BL + (ENT_IDX(e) - j * T_BL));
+        if (ent_regular(e))
+            dst[1 + k++] = (uint16_t)(((ENT_ALT(e) + ENT_REF(e) - 1u) << 14) | ((ENT_IDX(e) - j * T_BLU) << 4) | ent_code(e));
     }
     for (; k < K; k++) dst[1 + k] = T_NULL;
 }
@@ -1332,7 +1332,7 @@ cellector_status tiled_build(cellector_ctx *c)
     if (nloc >= (1ull << 28)) return ctx_fail(c, CELLECTOR_EINVAL, "tiled engine: more than 2^28 cells per shard");
     if (L >= (1ull << 28)) return ctx_fail(c, CELLECTOR_EINVAL, "tiled engine: more than 2^28 loci");
     c->t_nb = (uint32_t)((nloc + T_BC - 1) / T_BC);
-    c->t_nj = (uint32_t)((L + T_BL - 1) / T_BL);
+    c->t_nj = (uint32_t)((L + T_BLU - 1) / T_BLU);
     if (c->t_nb == 0) c->t_nb = 1;
     if (c->t_nj == 0) c->t_nj = 1;
     // Chunk groups: a multiple of the 8 XCDs (workgroup i runs on XCD i mod 8, so a group's workgroups share one L2).  The
@@ -1493,7 +1493,7 @@ cellector_status tiled_build(cellector_ctx *c)
     // tables: three log-pmf-only sets (posterior passes; set 0 also serves an EM pass without the expected column),
     // then one set of (log-pmf, expected) pairs; tail pad for the unconditional partial last table load
     const uint64_t tab_elems = (uint64_t)c->t_nj * TAB_ELEMS;
-    CHK(dev_alloc(c, &c->tab, 5 * tab_elems + 4 * T_THREADS));
+    CHK(dev_alloc(c, &c->tab, 4 * tab_elems + 4 * T_THREADS));
     c->tab_em = c->tab;
     c->tab_em_stride = 1;
     CHK(dev_alloc(c, &c->part, 3ull * 2 * c->t_groups * c->t_npad));
