@@ -106,7 +106,8 @@ struct cellector_ctx {
     uint64_t ovf_n = 0;
     double *ovf_tab = nullptr;       // [L][128] per-locus cumulative-log / expected tables for overflow entries
     double *ovf_etab = nullptr;      // [L][4] E(n), n = 5..8: compact copy for the cell side
-    int side_lds = 0;                // option "side_lds": dynamic LDS bytes requested by the cell-side overflow kernel (residency throttle)
+    int side_lds = -1;               // option "side_lds": dynamic LDS bytes requested by the cell-side overflow kernel (residency
+                                     // throttle; -1 = automatic)
     bool ovf_locus_pending = false;  // the side stream still owes this iteration's ovf_lp (event ev_join2)
     double *ovf_lp = nullptr;        // [ovf_n] the EM pass' overflow log-pmfs alone, by-locus order (locus pass)
     double *ovf_sum = nullptr;       // [3][2][nloc] per-cell sums of the overflow values (ll, expected) per table set

@@ -2,29 +2,29 @@
 //
 // Observation: under one (alpha_l, beta_l) the log-pmf of an entry depends only on (alt, ref), and vartrix counts
 // are tiny (n = alt+ref <= 4 for ~99 % of entries).  So per EM iteration and locus we tabulate the 14 log-pmfs of
-// n = 1..4 and the 4 expected terms and the matrix passes become pure table lookups:
+// n = 1..4 and the 4 expected terms (18 doubles per locus) and the matrix passes become pure table lookups:
 //
-//   cell pass   (get_cell_log_likelihoods, main.rs:541-591): the matrix is cut into (1024-cell block x 384-locus
+//   cell pass   (get_cell_log_likelihoods, main.rs:541-591): the matrix is cut into (1024-cell block x 639-locus
 //               chunk) tiles, stored in a sliced-ELLPACK form with a sorting window of one tile (SELL-64-1024): the
 //               cells of a tile are ordered by their entry count, every 64 of them form a slice whose rows (one per
 //               cell: cell id + entries) are padded to the slice's longest cell, so that all lanes of a wave run the
 //               SAME number of lookups — no divergence and ~10 % padding instead of the ~55 % idle lanes of a
 //               cell-per-lane walk in file order — and a lane fetches its row with one or two 16-byte loads.
-//               A u16 entry is the table index code * 384 + locus_in_chunk; padding points at a row of zeros.
-//               A 1024-thread workgroup owns four cell blocks and a group of chunks: the chunk's table lives in LDS as
-//               (log-pmf, expected term) PAIRS so that one ds_read_b128 serves both sums; a lane keeps its cell's
-//               entries of the tile in registers (prefetched two tiles ahead) and adds the tile's sum to the cell's
-//               accumulator in LDS (the lane <-> cell assignment changes from tile to tile).  The kernel is bound by
-//               the LDS pipe (random 16-byte lookups, ~12 clk per wave instruction: tools/probe/lds_probe.hip).
-//               No transcendental, no atomics; a cell's sum runs over its chunks in order and inside a chunk in
-//               ascending-locus order: bit-deterministic (the number of chunk groups fixes how the partials associate).
+//               A u16 entry is n-1 << 14 | locus slot << 4 | code; padding points at an all-zero slot.
+//               A persistent 1024-thread workgroup takes columns of four cell blocks and a group of chunks: the chunk's
+//               table lives in LDS locus-major (144 B per locus: the log-pmf and the expected term of an entry are two
+//               8-byte reads near each other); a lane keeps its cell's entries of the tile in registers (prefetched two
+//               tiles ahead) and adds the tile's sum to the cell's accumulator in LDS (the lane <-> cell assignment
+//               changes from tile to tile).  No transcendental, no atomics; a cell's sum runs over its chunks in order
+//               and inside a chunk in ascending-locus order: bit-deterministic (the number of chunk groups fixes how
+//               the partials associate).
 //   locus pass  (get_locus_log_likelihoods, main.rs:368-420): all outputs follow from the minority cells' entry counts per
 //               (locus, code): contributions are count x table value; the majority side is (static histogram - minority).
 //               The counts come either from walking only the excluded cells' CSR rows into LDS range histograms
 //               (k_minority_ranges: the usual case, a few percent of the matrix) or from streaming a compact CSC of
 //               24/32-bit entries (cell | code) past the exclusion bitmask in LDS (k_locus_stats2); chosen on the device.
-//   overflow    entries with n == 0 or n > 4 (~1 %) live in a small CSR/CSC in the v1 packed format; their values are
-//               computed once per pass in locus-major order and gathered.
+//   overflow    entries with n == 0 or n > 4 (~1 %) live in a small CSR/CSC in the v1 packed format; the cell side
+//               evaluates them itself, the locus side from per-locus cumulative-log tables (see below).
 #include <type_traits>
 
 #include "ctx.h"
@@ -66,9 +66,9 @@ __device__ __forceinline__ uint32_t ent_code(uint64_t e)
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// tables, laid out [chunk][row][locus_in_chunk] so that a chunk is one contiguous block the tile kernel copies
-// straight into LDS.  PAIRS: element = (log-pmf of the code, expected term of the code's n) as double2; else the
-// log-pmf alone.  Zero for masked loci (alpha < 0), for the padding beyond L and in row T_NCODE.
+// tables, laid out [chunk][locus slot][18] so that a chunk is one contiguous block the tile kernel copies straight into
+// LDS: per locus the 14 log-pmfs, then (PAIRS) the 4 expected terms.  All zero for masked loci (alpha < 0), for the
+// padding beyond L and in the last slot of every chunk (the padding entries' target).
 // ---------------------------------------------------------------------------------------------------------
 // In an EM iteration the kernel is the iteration's FIRST one: it then also forms alpha/beta (init_alpha_betas,
 // main.rs:598-611: alpha_l = (S_alt_l + 1) - sum over excluded cells, the subtrahend being the all-reduced ALT_MIN plane of
@@ -1538,7 +1538,11 @@ static void launch_overflow_cell(cellector_ctx *c, hipStream_t st, const double2
     const unsigned g = gcap(c->nloc, 256, 0x7fffffffu), eg = gcap(c->L * 16, 256, 0x7fffffffu);
     if (expected) {
         hipLaunchKernelGGL(k_ovf_tables_e, dim3(eg), dim3(256), 0, st, c->L, ab, c->ovf_nmask, c->ovf_tab, c->ovf_etab);
-        hipLaunchKernelGGL(k_ovf_cell_direct<true>, dim3(g), dim3(256), (size_t)c->side_lds, st, c->nloc, c->ovf_ell_ptr, c->ovf_ell, ab, c->lf,
+        // Residency throttle: a request for dynamic LDS it does not use leaves room for only ONE block of this kernel beside
+        // a tile workgroup (one wave per SIMD instead of two).  On a big shard the kernel still ends well inside the tile
+        // kernel and disturbs it less (cfg4: 2.83 -> 2.78 ms per iteration); a small shard's tile kernel is too short for that.
+        const size_t lds_req = c->side_lds >= 0 ? (size_t)c->side_lds : (st == c->side && c->nloc >= (1ull << 19) ? 5000 : 0);
+        hipLaunchKernelGGL(k_ovf_cell_direct<true>, dim3(g), dim3(256), lds_req, st, c->nloc, c->ovf_ell_ptr, c->ovf_ell, ab, c->lf,
                            c->ovf_etab, c->ovf_tab, o_ll, o_ell);
         if (c->ovf_n_tier[0])
             hipLaunchKernelGGL((k_ovf_cell_listed<true, false>), dim3(gcap(c->ovf_n_tier[0], 256, 0x7fffffffu)), dim3(256), 0, st,
