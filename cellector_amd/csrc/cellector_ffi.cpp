@@ -28,6 +28,8 @@ cellector_status ctx_fail(const cellector_ctx *c, cellector_status s, const char
 void timer_begin(cellector_ctx *c, int which)
 {
     if (!c->timing) return;
+    // an event pair costs a few microseconds of idle queue: level 2 keeps only the pair the roofline figure needs
+    if (c->timing == 2 && which != (c->engine == 2 ? CELLECTOR_K_TILE_LL : CELLECTOR_K_CELL_LL)) return;
     hipEvent_t a, b;
     if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
     c->timers[which].start.push_back(a);
@@ -37,6 +39,7 @@ void timer_begin(cellector_ctx *c, int which)
 void timer_end(cellector_ctx *c, int which)
 {
     if (!c->timing) return;
+    if (c->timing == 2 && which != (c->engine == 2 ? CELLECTOR_K_TILE_LL : CELLECTOR_K_CELL_LL)) return;
     KernelTimer &t = c->timers[which];
     if (t.stop.empty()) return;
     (void)hipEventRecord(t.stop.back(), c->stream);
@@ -196,10 +199,12 @@ cellector_status cellector_create(cellector_ctx **out, int device_id)
     bool ok = hipMalloc((void **)&c->lf, sizeof lf) == hipSuccess &&
               hipMemcpy(c->lf, lf, sizeof lf, hipMemcpyHostToDevice) == hipSuccess &&
               hipMalloc((void **)&c->d_counters, 8 * sizeof(uint32_t)) == hipSuccess &&
-              hipMalloc((void **)&c->sel_hist, 3 * SEL_T * 256 * sizeof(uint32_t)) == hipSuccess &&
+              hipMalloc((void **)&c->sel_hist, CELLECTOR_SEL_HIST_WORDS * sizeof(uint32_t)) == hipSuccess &&
+              hipMemset(c->sel_hist, 0, CELLECTOR_SEL_HIST_WORDS * sizeof(uint32_t)) == hipSuccess &&  // k_sel_finish re-zeroes
               hipMalloc((void **)&c->sel_state, 4 * SEL_T * sizeof(uint64_t)) == hipSuccess &&
               hipMalloc((void **)&c->sel_out, 16 * sizeof(double)) == hipSuccess &&
               hipHostMalloc((void **)&c->h_sel, 32 * sizeof(double)) == hipSuccess &&
+              (memset(c->h_sel, 0, 32 * sizeof(double)), true) &&
               hipHostGetDevicePointer((void **)&c->h_sum_dev, c->h_sel, 0) == hipSuccess &&
               create_side_stream(&c->side) &&
               hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) == hipSuccess &&
@@ -222,6 +227,7 @@ void cellector_destroy(cellector_ctx *c)
     timer_collect(c);
     free_matrix(c);
     dev_free(c->lf); dev_free(c->d_counters); dev_free(c->sel_hist); dev_free(c->sel_state); dev_free(c->sel_out);
+    dev_free(c->sel_list);
     if (c->h_sel) (void)hipHostFree(c->h_sel);
     if (c->side) (void)hipStreamDestroy(c->side);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
@@ -245,7 +251,7 @@ cellector_status cellector_set_option(cellector_ctx *c, const char *key, int64_t
 {
     if (!c || !key) return CELLECTOR_EINVAL;
     if (!strcmp(key, "compute_expected")) c->compute_expected = v != 0;
-    else if (!strcmp(key, "timing")) c->timing = v != 0;
+    else if (!strcmp(key, "timing")) c->timing = v < 0 ? 0 : (v > 2 ? 2 : (int)v);
     else if (!strcmp(key, "keep_coo")) c->keep_coo = v != 0;
     else if (!strcmp(key, "overlap")) {
         if (v < 0 || v > 2) return ctx_fail(c, CELLECTOR_EINVAL, "overlap must be 0, 1 or 2");
@@ -592,11 +598,33 @@ cellector_status cellector_em_finish(cellector_ctx *c, cellector_iter_summary *o
     SETDEV(c);
     CHK(launch_locus_filter(c));
     CHK(launch_iter_summary(c));
-    HIPCHK(c, hipEventRecord(c->ev_sum, c->stream));
     // the next iteration's first kernel is queued behind the summary: it runs while the host waits for the summary, wakes
     // up and decides (should the loop end here, the tables it built are simply never used)
     if (c->engine == 2 && c->tiled_ready) CHK(tiled_prebuild_tables(c));
-    HIPCHK(c, hipEventSynchronize(c->ev_sum));  // the iteration's only host synchronisation
+    HIPCHK(c, hipEventRecord(c->ev_sum, c->stream));  // (behind that kernel: an event between the two idles the queue ~6 us)
+    // The iteration's only host synchronisation.  The summary kernel stores its sequence number behind the values in
+    // pinned memory: polling that wakes the host a few tens of microseconds before hipEventSynchronize returns, and the
+    // next iteration's tile kernel is the next thing the GPU waits for.  (The event stays the fallback: it is polled too,
+    // and waited for once the summary is 20 ms late.)
+    {
+        const double want = (double)c->sum_seq;
+        const uint64_t *seq = reinterpret_cast<const uint64_t *>(c->h_sel + CELLECTOR_SUM_SEQ);
+        const auto t0 = std::chrono::steady_clock::now();
+        for (uint32_t spin = 1;; spin++) {
+            const uint64_t bits = __atomic_load_n(seq, __ATOMIC_ACQUIRE);
+            double have;
+            memcpy(&have, &bits, sizeof have);
+            if (have == want) break;
+            if ((spin & 0xfffu) == 0) {
+                if (hipEventQuery(c->ev_sum) == hipSuccess) break;
+                if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) {
+                    HIPCHK(c, hipEventSynchronize(c->ev_sum));
+                    break;
+                }
+            }
+            __builtin_ia32_pause();
+        }
+    }
     double cnt[LC_COUNTERS];
     uint32_t dc[8] = {0};
     for (int i = 0; i < LC_COUNTERS; i++) cnt[i] = c->h_sel[i];

@@ -50,7 +50,7 @@ struct cellector_ctx {
 
     // options
     bool compute_expected = true;
-    bool timing = false;
+    int timing = 0;  // 0 off, 1 every timed region, 2 only the dominant kernel of the engine
     bool keep_coo = true;
 
     // shard
@@ -142,11 +142,14 @@ struct cellector_ctx {
                                      // 2 = minority-driven tally over the by-cell CSR
 
     // order-statistic workspace
-    uint32_t *sel_hist = nullptr;   // [3][SEL_T][256] rotating: previous / this / next pass
-    uint64_t *sel_state = nullptr;  // [2][SEL_T][2] prefix, remaining rank of the previous / this pass
+    uint32_t *sel_hist = nullptr;   // [4096] top-bits histogram, [SEL_T][1024] next-bits histograms, [1] list length (+ pad)
+    uint64_t *sel_state = nullptr;  // [2][SEL_T][2] prefix, remaining rank after the first / second step
+    uint64_t *sel_list = nullptr;   // keys that carry a target's 22-bit prefix (capacity: all keys)
+    uint64_t sel_list_cap = 0;
     double *sel_out = nullptr;      // [16] device: [0..5] order statistics, [8..10] median, iqr, threshold
     double *h_sel = nullptr;        // pinned [32]: iteration summary written by k_iter_summary, read in em_finish
     double *h_sum_dev = nullptr;    // the device's address of h_sel
+    uint64_t sum_seq = 0;           // number of summaries queued; h_sel[CELLECTOR_SUM_SEQ] = the last one that arrived
     bool tables_prebuilt = false;   // the next iteration's k_build_tables is already queued / done (em_finish)
     bool prebuilt_expected = false; // ... with this value of compute_expected
     bool work_zeroed = false;       // tile_work was reset by this iteration's k_alpha_beta
@@ -161,6 +164,8 @@ struct cellector_ctx {
 };
 
 #define SEL_T 6
+#define CELLECTOR_SUM_SEQ 31
+#define CELLECTOR_SEL_HIST_WORDS (4096 + SEL_T * 1024 + 64)
 
 // ---- error plumbing ---------------------------------------------------------------------------
 cellector_status ctx_fail(const cellector_ctx *c, cellector_status s, const char *fmt, ...);

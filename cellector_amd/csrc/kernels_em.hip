@@ -309,14 +309,18 @@ __global__ void k_final_tallies(uint64_t n, uint64_t total_loci, const uint32_t 
     if (ref[i]) atomicAdd(&out[base + total_loci + l], (unsigned long long)ref[i]);
 }
 
-// the iteration's summary, written straight into pinned host memory (one kernel instead of three small copies)
+// the iteration's summary, written straight into pinned host memory (one kernel instead of three small copies); the
+// sequence number goes last, released at system scope: the host polls it (cellector_em_finish)
 __global__ void k_iter_summary(const double *__restrict__ xl_counters, const uint32_t *__restrict__ d_counters,
-                               const double *__restrict__ sel, double *__restrict__ h_sum)
+                               const double *__restrict__ sel, double *__restrict__ h_sum, double seq)
 {
     const int t = threadIdx.x;
     if (t < LC_COUNTERS) h_sum[t] = xl_counters[t];
     else if (t == LC_COUNTERS) h_sum[t] = (double)d_counters[DC_N_FILTERED];
     else if (t < LC_COUNTERS + 4) h_sum[t] = sel[t - LC_COUNTERS - 1];  // median, iqr, threshold
+    __threadfence_system();
+    __syncthreads();
+    if (t == 0) __hip_atomic_store(&h_sum[CELLECTOR_SUM_SEQ], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // ===================================================================================================
@@ -414,7 +418,7 @@ cellector_status launch_locus_filter(cellector_ctx *c)
 cellector_status launch_iter_summary(cellector_ctx *c)
 {
     hipLaunchKernelGGL(k_iter_summary, dim3(1), dim3(64), 0, c->stream, c->x_locus + (uint64_t)LB_PLANES * c->L, c->d_counters,
-                       c->sel_out + 8, c->h_sum_dev);
+                       c->sel_out + 8, c->h_sum_dev, (double)++c->sum_seq);
     HIPCHK(c, hipGetLastError());
     return CELLECTOR_OK;
 }

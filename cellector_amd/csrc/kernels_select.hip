@@ -1,18 +1,30 @@
 // Exact order statistics of N f64 keys on the device (statrs Data::median / Data::quantile need the
 // values at up to six ranks: main.rs:324-327).
 //
-// MSB-first radix select, 8 bits per pass, all SEL_T target ranks refined together: one kernel per pass.  Keys that match
-// a target's resolved prefix vote into that target's 256-bin LDS histogram (votes aggregated per wave before the LDS
-// atomic, then per block before the global atomic); targets that still share a prefix share one histogram.  The
-// selection step between two passes (walk each histogram to the bin holding the target rank) is done redundantly by
-// wave 0 of every block at the start of the next pass — a separate single-wave kernel per pass cost more in launch gaps
-// than the redundant 6 KB histogram read — with three rotating histogram buffers (read the previous pass', fill this
-// pass', block 0 clears the next pass') and two state buffers.  The last step runs inside the threshold kernel.  The
-// results stay in device memory: the flagging kernel reads the threshold there, so the phase needs no host round trip.
+// MSB-first radix select in four kernels, all SEL_T target ranks refined together, no host round trip:
+//   k_sel_top     histogram of the top 12 bits (sign + exponent) of every key: a handful of bins in practice, so a wave
+//                 whose keys agree votes with one LDS atomic;
+//   k_sel_mid     the step on that histogram (wave 0 of every block, redundantly: a kernel of its own per step costs more
+//                 in launch gaps than the re-read of a 16 KB histogram), then the histogram of the next 10 bits of the
+//                 keys that carry a target's 12-bit prefix (targets that share a prefix share a histogram);
+//   k_sel_gather  the step on those histograms, then the keys that carry a target's 22-bit prefix are appended to a list
+//                 (N / 2000 of them per target when the mantissa bits are spread; all of them in the worst case);
+//   k_sel_finish  one workgroup: the remaining 42 bits, 7 per step, over the list, then the quartile / threshold
+//                 arithmetic.
+// Few workgroups on purpose (SEL_GRID): a workgroup's histogram goes to the global one with one atomic per non-empty
+// bin, and atomics to the same few cache lines run one after the other — 1024 workgroups x 256 bins took 40 us.
+// The results stay in device memory: the flagging kernel reads the threshold there.  The histograms are zero when a
+// context is created and k_sel_finish leaves them zero.
 #include "ctx.h"
 
-#define SEL_BLOCK 256
-#define SEL_PASSES 8
+#define SEL_THREADS 1024
+#define SEL_GRID 128
+#define SEL_NB0 4096  // bins of bits 63..52
+#define SEL_NB1 1024  // bins of bits 51..42
+#define SEL_SH0 52
+#define SEL_SH1 42
+#define SEL_FIN_BITS 7
+#define SEL_FIN_STEPS 6  // 6 x 7 = the 42 low bits
 
 __device__ __forceinline__ uint64_t key_of(double x)
 {
@@ -25,174 +37,454 @@ __device__ __forceinline__ double value_of(uint64_t k)
     return __longlong_as_double((long long)u);
 }
 
-// state[t] = {prefix (resolved high bits, low bits zero), remaining rank inside that prefix}
 struct sel_ranks_t { uint64_t r[SEL_T]; };
 
-// one wave: for each target find the bin of its (leader's) histogram that holds the remaining rank.
-// Lane i owns bins 4i..4i+3; a shuffle scan over the lane sums locates the lane, then the bin inside it.
-// `pass` = the pass that filled `hist`; newp / newr are valid in every lane.
-__device__ __forceinline__ void sel_step(int lane, int pass, const uint64_t *__restrict__ state, const uint32_t *__restrict__ hist,
-                                         uint64_t newp[SEL_T], uint64_t newr[SEL_T])
+// one wave, one histogram of NB bins (lane owns NB/64 consecutive ones): lane sums and their inclusive scan
+template <int NB>
+__device__ __forceinline__ void sel_scan(int lane, const uint32_t *hist, uint64_t &lsum, uint64_t &inc)
 {
-    uint64_t prefix[SEL_T], rank[SEL_T];
-#pragma unroll
-    for (int t = 0; t < SEL_T; t++) {
-        prefix[t] = state[2 * t];
-        rank[t] = state[2 * t + 1];
+    constexpr int PER = NB / 64;
+    static_assert(PER % 4 == 0, "uint4 reads");
+    const uint4 *mine = reinterpret_cast<const uint4 *>(hist + lane * PER);
+    uint64_t s = 0;
+#pragma unroll 4
+    for (int i = 0; i < PER / 4; i++) {
+        const uint4 h = mine[i];
+        s += (uint64_t)h.x + h.y + h.z + h.w;
     }
-    const int shift = 56 - 8 * pass;
+    lsum = s;
+    uint64_t v = s;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint64_t o = (uint64_t)__shfl_up((long long)v, off, 64);
+        if (lane >= off) v += o;
+    }
+    inc = v;
+}
+// ... and the bin that holds 0-based rank r, with the number of keys below that bin (valid in every lane)
+template <int NB>
+__device__ __forceinline__ void sel_pick(int lane, const uint32_t *hist, uint64_t lsum, uint64_t inc, uint64_t r, uint32_t &bin,
+                                         uint64_t &below)
+{
+    constexpr int PER = NB / 64;
+    const uint64_t exc = inc - lsum;
+    // the lane whose bins contain the rank (the last lane if counts are short: defensive, cannot happen)
+    const bool mine = (exc <= r && r < inc) || (lane == 63 && r >= inc);
+    uint32_t d = 0;
+    uint64_t cum = exc;
+    if (mine) {
+        d = (uint32_t)(lane * PER);
+        for (int i = 0; i < PER - 1; i++) {
+            const uint32_t h = hist[lane * PER + i];
+            if (cum + h > r) break;
+            cum += h;
+            d++;
+        }
+    }
+    const unsigned long long who = __ballot(mine);
+    const int src = __ffsll((long long)who) - 1;
+    bin = (uint32_t)__shfl((int)d, src, 64);
+    below = (uint64_t)__shfl((long long)cum, src, 64);
+}
+
+// targets with equal prefixes share the histogram of the first of them
+__device__ __forceinline__ void sel_leaders(const uint64_t prefix[SEL_T], int leader[SEL_T])
+{
 #pragma unroll
     for (int t = 0; t < SEL_T; t++) {
         int ld = t;
 #pragma unroll
         for (int u = SEL_T - 1; u >= 0; u--)
             if (u < t && prefix[u] == prefix[t]) ld = u;
-        const uint4 h4 = reinterpret_cast<const uint4 *>(hist + ld * 256)[lane];
-        const uint32_t hs[4] = {h4.x, h4.y, h4.z, h4.w};
-        const uint32_t lsum = hs[0] + hs[1] + hs[2] + hs[3];
-        uint32_t inc = lsum;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const uint32_t o = __shfl_up(inc, off, 64);
-            if (lane >= off) inc += o;
-        }
-        const uint64_t exc = inc - lsum;
-        // the lane whose bins contain the rank (the last lane if counts are short: defensive, cannot happen)
-        const bool mine = (exc <= rank[t] && rank[t] < (uint64_t)inc) || (lane == 63 && rank[t] >= (uint64_t)inc);
-        uint32_t d = 0;
-        uint64_t cum = exc;
-        if (mine) {
-            d = 4 * lane;
-#pragma unroll
-            for (int q = 0; q < 3; q++) {
-                if (cum + hs[q] <= rank[t] && d == (uint32_t)(4 * lane + q)) { cum += hs[q]; d++; }
-            }
-        }
-        const unsigned long long who = __ballot(mine);
-        const int src = __ffsll((long long)who) - 1;
-        const uint32_t dsel = (uint32_t)__shfl((int)d, src, 64);
-        const uint64_t cumsel = (uint64_t)__shfl((long long)cum, src, 64);
-        newp[t] = prefix[t] | ((uint64_t)dsel << shift);
-        newr[t] = rank[t] - cumsel;
+        leader[t] = ld;
     }
 }
 
-// One pass: (1) the selection step on the previous pass' histogram (wave 0 of every block, redundantly; pass 0 starts from
-// the ranks), (2) the histogram of this pass' digit of the keys that match a target's resolved prefix.
-__global__ __launch_bounds__(SEL_BLOCK) void k_sel_pass(const double *__restrict__ keys, uint64_t n, int pass, sel_ranks_t ranks,
-                                                        const uint64_t *__restrict__ state_prev, uint64_t *__restrict__ state_cur,
-                                                        const uint32_t *__restrict__ hist_prev, uint32_t *__restrict__ hist_cur,
-                                                        uint32_t *__restrict__ hist_next)
+__global__ __launch_bounds__(SEL_THREADS) void k_sel_top(const double *__restrict__ keys, uint64_t n, uint32_t *__restrict__ hist0)
 {
-    __shared__ uint32_t h[SEL_T][256];
-    __shared__ uint64_t prefix[SEL_T];
+    __shared__ uint32_t h[SEL_NB0];
+    for (int i = threadIdx.x; i < SEL_NB0; i += SEL_THREADS) h[i] = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const uint64_t stride = (uint64_t)gridDim.x * SEL_THREADS;
+    for (uint64_t base = (uint64_t)blockIdx.x * SEL_THREADS; base < n; base += 4 * stride) {
+        uint64_t k[4];
+        bool ok[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint64_t i = base + u * stride + threadIdx.x;
+            ok[u] = i < n;
+            k[u] = ok[u] ? key_of(keys[i]) : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t d = (uint32_t)(k[u] >> SEL_SH0);
+            const unsigned long long act = __ballot(ok[u]);
+            if (!act) continue;  // wave-uniform
+            const int src = __ffsll((long long)act) - 1;
+            const uint32_t d0 = (uint32_t)__shfl((int)d, src, 64);
+            const unsigned long long same = __ballot(ok[u] && d == d0);
+            if (same == act) {
+                if (lane == src) atomicAdd(&h[d0], (uint32_t)__popcll(act));
+            } else if (ok[u]) {
+                atomicAdd(&h[d], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < SEL_NB0; i += SEL_THREADS) {
+        const uint32_t v = h[i];
+        if (v) atomicAdd(&hist0[i], v);  // agent scope
+    }
+}
+
+// state = SEL_T x {prefix (resolved high bits, low bits zero), remaining rank inside that prefix}
+__global__ __launch_bounds__(SEL_THREADS) void k_sel_mid(const double *__restrict__ keys, uint64_t n, sel_ranks_t ranks,
+                                                         const uint32_t *__restrict__ hist0, uint64_t *__restrict__ state1,
+                                                         uint32_t *__restrict__ hist1)
+{
+    __shared__ uint32_t h[SEL_T][SEL_NB1];
+    __shared__ uint32_t top[SEL_T];
     __shared__ int leader[SEL_T];
-    for (int i = threadIdx.x; i < SEL_T * 256; i += SEL_BLOCK) (&h[0][0])[i] = 0;
-    if (blockIdx.x == 0)
-        for (int i = threadIdx.x; i < SEL_T * 256; i += SEL_BLOCK) hist_next[i] = 0;  // nobody touches it during this pass
+    for (int i = threadIdx.x; i < SEL_T * SEL_NB1; i += SEL_THREADS) (&h[0][0])[i] = 0;
     if (threadIdx.x < 64) {
-        uint64_t np[SEL_T], nr[SEL_T];
-        if (pass == 0) {
+        const int lane = (int)threadIdx.x;
+        uint64_t lsum, inc, np[SEL_T], nr[SEL_T];
+        sel_scan<SEL_NB0>(lane, hist0, lsum, inc);
 #pragma unroll
-            for (int t = 0; t < SEL_T; t++) { np[t] = 0; nr[t] = ranks.r[t]; }
-        } else {
-            sel_step((int)threadIdx.x, pass - 1, state_prev, hist_prev, np, nr);
-        }
-        if (threadIdx.x == 0) {
-#pragma unroll
-            for (int t = 0; t < SEL_T; t++) {
-                prefix[t] = np[t];
-                if (blockIdx.x == 0) { state_cur[2 * t] = np[t]; state_cur[2 * t + 1] = nr[t]; }
-            }
-            for (int t = 0; t < SEL_T; t++) {
-                int ld = t;
-                for (int u = 0; u < t; u++)
-                    if (np[u] == np[t]) { ld = u; break; }
-                leader[t] = ld;
-            }
-        }
-    }
-    __syncthreads();
-    const int shift = 56 - 8 * pass;
-    const uint64_t himask = pass == 0 ? 0ull : (~0ull << (shift + 8));
-    for (uint64_t i = (uint64_t)blockIdx.x * SEL_BLOCK + threadIdx.x; i < n; i += (uint64_t)gridDim.x * SEL_BLOCK) {
-        const uint64_t k = key_of(keys[i]);
-        const uint32_t digit = (uint32_t)(k >> shift) & 0xffu;
         for (int t = 0; t < SEL_T; t++) {
-            if (leader[t] != t) continue;  // block-uniform
-            bool match = (k & himask) == prefix[t];
-            // wave-aggregated vote: one LDS atomic per distinct digit per wave
-            unsigned long long todo = __ballot(match);
-            while (todo) {
-                const int src = __ffsll((long long)todo) - 1;
-                const uint32_t d0 = (uint32_t)__shfl((int)digit, src, 64);
-                const unsigned long long same = __ballot(match && digit == d0) & todo;
-                if ((threadIdx.x & 63) == src) atomicAdd(&h[t][d0], (uint32_t)__popcll(same));
-                todo &= ~same;
+            uint32_t bin;
+            uint64_t below;
+            sel_pick<SEL_NB0>(lane, hist0, lsum, inc, ranks.r[t], bin, below);
+            np[t] = (uint64_t)bin << SEL_SH0;
+            nr[t] = ranks.r[t] - below;
+        }
+        if (lane == 0) {
+            int ld[SEL_T];
+            sel_leaders(np, ld);
+#pragma unroll
+            for (int t = 0; t < SEL_T; t++) {
+                top[t] = (uint32_t)(np[t] >> SEL_SH0);
+                leader[t] = ld[t];
+                if (blockIdx.x == 0) { state1[2 * t] = np[t]; state1[2 * t + 1] = nr[t]; }
             }
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < SEL_T * 256; i += SEL_BLOCK) {
+    uint32_t ltop[SEL_T];
+    bool lead[SEL_T];
+#pragma unroll
+    for (int t = 0; t < SEL_T; t++) { ltop[t] = top[t]; lead[t] = leader[t] == t; }
+    const uint64_t stride = (uint64_t)gridDim.x * SEL_THREADS;
+    for (uint64_t base = (uint64_t)blockIdx.x * SEL_THREADS; base < n; base += 4 * stride) {
+        uint64_t k[4];
+        bool ok[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint64_t i = base + u * stride + threadIdx.x;
+            ok[u] = i < n;
+            k[u] = ok[u] ? key_of(keys[i]) : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            if (!ok[u]) continue;
+            const uint32_t hi = (uint32_t)(k[u] >> SEL_SH0), d = (uint32_t)(k[u] >> SEL_SH1) & (SEL_NB1 - 1);
+#pragma unroll
+            for (int t = 0; t < SEL_T; t++)
+                if (lead[t] && hi == ltop[t]) atomicAdd(&h[t][d], 1u);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < SEL_T * SEL_NB1; i += SEL_THREADS) {
         const uint32_t v = (&h[0][0])[i];
-        if (v) atomicAdd(&hist_cur[i], v);  // agent scope
+        if (v) atomicAdd(&hist1[i], v);
+    }
+}
+
+__global__ __launch_bounds__(SEL_THREADS) void k_sel_gather(const double *__restrict__ keys, uint64_t n,
+                                                            const uint64_t *__restrict__ state1, const uint32_t *__restrict__ hist1,
+                                                            uint64_t *__restrict__ state2, uint64_t *__restrict__ list,
+                                                            uint32_t *__restrict__ count)
+{
+    __shared__ uint32_t pre[SEL_T];  // the 22 resolved bits
+    __shared__ uint64_t buf[4 * SEL_THREADS];
+    __shared__ uint32_t lcount, gbase;
+    if (threadIdx.x == 0) lcount = 0;
+    if (threadIdx.x < 64) {
+        const int lane = (int)threadIdx.x;
+        uint64_t p1[SEL_T], r1[SEL_T], np[SEL_T], nr[SEL_T];
+        int ld[SEL_T];
+#pragma unroll
+        for (int t = 0; t < SEL_T; t++) { p1[t] = state1[2 * t]; r1[t] = state1[2 * t + 1]; }
+        sel_leaders(p1, ld);
+#pragma unroll
+        for (int t = 0; t < SEL_T; t++) {
+            const uint32_t *hist = hist1 + ld[t] * SEL_NB1;
+            uint64_t lsum, inc, below;
+            uint32_t bin;
+            sel_scan<SEL_NB1>(lane, hist, lsum, inc);
+            sel_pick<SEL_NB1>(lane, hist, lsum, inc, r1[t], bin, below);
+            np[t] = p1[t] | ((uint64_t)bin << SEL_SH1);
+            nr[t] = r1[t] - below;
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int t = 0; t < SEL_T; t++) {
+                pre[t] = (uint32_t)(np[t] >> SEL_SH1);
+                if (blockIdx.x == 0) { state2[2 * t] = np[t]; state2[2 * t + 1] = nr[t]; }
+            }
+        }
+    }
+    __syncthreads();
+    uint32_t lp[SEL_T];
+#pragma unroll
+    for (int t = 0; t < SEL_T; t++) lp[t] = pre[t];
+    // matches of a round (4 keys per thread) go to LDS first, then to the list with ONE global atomic per workgroup:
+    // returning atomics to one address run at ~14 ns each (one per matching wave took 140 us at 10^4 matches)
+    const int lane = threadIdx.x & 63;
+    const uint64_t stride = (uint64_t)gridDim.x * SEL_THREADS;
+    for (uint64_t base = (uint64_t)blockIdx.x * SEL_THREADS; base < n; base += 4 * stride) {
+        uint64_t k[4];
+        bool ok[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint64_t i = base + u * stride + threadIdx.x;
+            ok[u] = i < n;
+            k[u] = ok[u] ? key_of(keys[i]) : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t hi = (uint32_t)(k[u] >> SEL_SH1);
+            bool m = false;
+#pragma unroll
+            for (int t = 0; t < SEL_T; t++) m |= hi == lp[t];
+            m &= ok[u];
+            const unsigned long long mm = __ballot(m);
+            if (!mm) continue;  // wave-uniform
+            const int src = __ffsll((long long)mm) - 1;
+            uint32_t at = 0;
+            if (lane == src) at = atomicAdd(&lcount, (uint32_t)__popcll(mm));
+            at = (uint32_t)__shfl((int)at, src, 64);
+            if (m) buf[at + (uint32_t)__popcll(mm & ((1ull << lane) - 1ull))] = k[u];
+        }
+        __syncthreads();
+        const uint32_t got = lcount;
+        if (threadIdx.x == 0 && got) gbase = atomicAdd(count, got);
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < got; i += SEL_THREADS) list[gbase + i] = buf[i];
+        if (threadIdx.x == 0) lcount = 0;
+        __syncthreads();
     }
 }
 
 // statrs Data::median / quantile and the threshold of main.rs:328-329 from the six order statistics,
 // in the reference's operation order: out = {median, iqr, threshold}
 struct sel_quart_t { double h1, h3; int64_t hf1, hf3; uint64_t n; double iqr_multiple; };
-// one wave: the last selection step (the six order statistics -> v[0..5]), then the threshold arithmetic -> out[0..2]
-__global__ void k_threshold(sel_quart_t q, const uint64_t *__restrict__ state_last, const uint32_t *__restrict__ hist_last,
-                            double *__restrict__ v, double *__restrict__ out)
+
+// one workgroup: the low 42 bits over the gathered keys (the six order statistics -> v[0..5]), then the threshold
+// arithmetic -> out[0..2].  After the first step the keys that still carry a target's prefix (1/128 of the list when the
+// bits are spread) move to LDS and the later steps run there; ties that do not fit stay in the global list.
+#define SEL_FIN_CAP 4096
+#define SEL_FIN_DIRECT 256  // survivors ranked by counting instead of further steps
+__device__ __forceinline__ void sel_fin_vote(uint64_t k, int shift, const uint64_t hi[SEL_T], const bool lead[SEL_T],
+                                             uint32_t (*h)[1 << SEL_FIN_BITS])
 {
-    uint64_t np[SEL_T], nr[SEL_T];
-    sel_step((int)threadIdx.x, SEL_PASSES - 1, state_last, hist_last, np, nr);
-    if (threadIdx.x != 0) return;
+    const uint32_t d = (uint32_t)(k >> shift) & ((1u << SEL_FIN_BITS) - 1u);
+    const uint64_t kh = k >> (shift + SEL_FIN_BITS);
 #pragma unroll
-    for (int t = 0; t < SEL_T; t++) v[t] = value_of(np[t]);
-    const double median = (q.n % 2 != 0) ? v[1] : (v[0] + v[1]) / 2.0;
+    for (int t = 0; t < SEL_T; t++)
+        if (lead[t] && kh == hi[t]) atomicAdd(&h[t][d], 1u);
+}
+__global__ __launch_bounds__(SEL_THREADS) void k_sel_finish(sel_quart_t q, const uint64_t *__restrict__ state2,
+                                                            const uint64_t *__restrict__ list, const uint32_t *count,
+                                                            uint32_t *scratch /* holds *count */, double *__restrict__ v,
+                                                            double *__restrict__ out)
+{
+    constexpr int NB = 1 << SEL_FIN_BITS;
+    static_assert(NB == 128, "a lane owns two bins in the step below");
+    __shared__ uint32_t h[SEL_T][NB];
+    __shared__ uint64_t st[2 * SEL_T];
+    __shared__ int leader[SEL_T];
+    __shared__ uint64_t cache[SEL_FIN_CAP];
+    __shared__ uint32_t n_cache;
+    const uint32_t m = *count;
+    // the histograms and the list length are zero again for the next call (the earlier kernels are done with them: this
+    // one is the last of the chain; `count` is inside the scratch block and was read above)
+    __syncthreads();
+    for (int i = threadIdx.x; i < CELLECTOR_SEL_HIST_WORDS; i += SEL_THREADS) scratch[i] = 0;
+    bool cached = false;  // workgroup-uniform: the keys still in play are cache[0 .. n_cache)
+    // a list of up to 16 keys per thread is read ONCE, all loads in flight together (one workgroup reading the list four
+    // keys at a time, twice, was 16 us of load latency); a longer one is streamed in both passes of the first step
+    constexpr int FIN_REG = 16;
+    const bool in_regs = m <= FIN_REG * SEL_THREADS;
+    uint64_t kr[FIN_REG];
+    if (in_regs) {
+#pragma unroll
+        for (int u = 0; u < FIN_REG; u++) {
+            const uint32_t i = u * SEL_THREADS + threadIdx.x;
+            kr[u] = i < m ? list[i] : 0;
+        }
+    }
+    if (threadIdx.x < 2 * SEL_T) st[threadIdx.x] = state2[threadIdx.x];
+    __syncthreads();
+    for (int step = 0; step < SEL_FIN_STEPS; step++) {
+        const int shift = SEL_SH1 - SEL_FIN_BITS * (step + 1);
+        for (int i = threadIdx.x; i < SEL_T * NB; i += SEL_THREADS) (&h[0][0])[i] = 0;
+        if (threadIdx.x == 0) {
+            uint64_t p[SEL_T];
+            int ld[SEL_T];
+#pragma unroll
+            for (int t = 0; t < SEL_T; t++) p[t] = st[2 * t];
+            sel_leaders(p, ld);
+#pragma unroll
+            for (int t = 0; t < SEL_T; t++) leader[t] = ld[t];
+        }
+        __syncthreads();
+        uint64_t hi[SEL_T];
+        bool lead[SEL_T];
+#pragma unroll
+        for (int t = 0; t < SEL_T; t++) { hi[t] = st[2 * t] >> (shift + SEL_FIN_BITS); lead[t] = leader[t] == t; }
+        if (cached) {
+            const uint32_t nc = n_cache;
+            for (uint32_t i = threadIdx.x; i < nc; i += SEL_THREADS) sel_fin_vote(cache[i], shift, hi, lead, h);
+        } else if (in_regs) {
+#pragma unroll
+            for (int u = 0; u < FIN_REG; u++)
+                if (u * SEL_THREADS + threadIdx.x < m) sel_fin_vote(kr[u], shift, hi, lead, h);
+        } else {
+            for (uint32_t i0 = 0; i0 < m; i0 += 4 * SEL_THREADS) {  // four loads in flight
+                uint64_t k[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const uint32_t i = i0 + u * SEL_THREADS + threadIdx.x;
+                    k[u] = i < m ? list[i] : 0;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                    if (i0 + u * SEL_THREADS + threadIdx.x < m) sel_fin_vote(k[u], shift, hi, lead, h);
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0 && !cached) n_cache = 0;
+        if (threadIdx.x < 64) {  // lane owns bins 2 lane, 2 lane + 1
+            const int lane = (int)threadIdx.x;
+            uint64_t np[SEL_T], nr[SEL_T];
+#pragma unroll
+            for (int t = 0; t < SEL_T; t++) {
+                const uint32_t *hist = &h[leader[t]][0];
+                const uint64_t r = st[2 * t + 1];
+                const uint32_t h0 = hist[2 * lane], h1 = hist[2 * lane + 1];
+                const uint64_t lsum = (uint64_t)h0 + h1;
+                uint64_t inc = lsum;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const uint64_t o = (uint64_t)__shfl_up((long long)inc, off, 64);
+                    if (lane >= off) inc += o;
+                }
+                const uint64_t exc = inc - lsum;
+                const bool mine = (exc <= r && r < inc) || (lane == 63 && r >= inc);
+                const bool second = mine && exc + h0 <= r;
+                const uint32_t d = (uint32_t)(2 * lane + (second ? 1 : 0));
+                const uint64_t cum = exc + (second ? h0 : 0);
+                const unsigned long long who = __ballot(mine);
+                const int src = __ffsll((long long)who) - 1;
+                const uint32_t dsel = (uint32_t)__shfl((int)d, src, 64);
+                const uint64_t csel = (uint64_t)__shfl((long long)cum, src, 64);
+                np[t] = st[2 * t] | ((uint64_t)dsel << shift);
+                nr[t] = r - csel;
+            }
+            if (lane == 0) {
+#pragma unroll
+                for (int t = 0; t < SEL_T; t++) { st[2 * t] = np[t]; st[2 * t + 1] = nr[t]; }
+            }
+        }
+        __syncthreads();
+        if (!cached && step + 1 < SEL_FIN_STEPS) {
+            // the survivors of this step: how many is known from the histograms, so the decision is uniform
+            uint64_t keep = 0;
+#pragma unroll
+            for (int t = 0; t < SEL_T; t++)
+                if (leader[t] == t || (st[2 * t] != st[2 * leader[t]]))  // one count per distinct new prefix
+                    keep += h[leader[t]][(uint32_t)(st[2 * t] >> shift) & (NB - 1)];
+            // (targets that shared a histogram and still share the prefix were counted once; targets that split were
+            //  counted each: keep >= the number of distinct survivors)
+            if (keep <= SEL_FIN_CAP) {
+                uint64_t pre[SEL_T];
+#pragma unroll
+                for (int t = 0; t < SEL_T; t++) pre[t] = st[2 * t] >> shift;
+                if (in_regs) {
+#pragma unroll
+                    for (int u = 0; u < FIN_REG; u++) {
+                        bool mt = false;
+#pragma unroll
+                        for (int t = 0; t < SEL_T; t++) mt |= (kr[u] >> shift) == pre[t];
+                        if (mt && u * SEL_THREADS + threadIdx.x < m) cache[atomicAdd(&n_cache, 1u)] = kr[u];
+                    }
+                } else {
+                    for (uint32_t i0 = 0; i0 < m; i0 += 4 * SEL_THREADS) {
+                        uint64_t k[4];
+#pragma unroll
+                        for (int u = 0; u < 4; u++) {
+                            const uint32_t i = i0 + u * SEL_THREADS + threadIdx.x;
+                            k[u] = i < m ? list[i] : 0;
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; u++) {
+                            bool mt = false;
+#pragma unroll
+                            for (int t = 0; t < SEL_T; t++) mt |= (k[u] >> shift) == pre[t];
+                            if (mt && i0 + u * SEL_THREADS + threadIdx.x < m) cache[atomicAdd(&n_cache, 1u)] = k[u];
+                        }
+                    }
+                }
+                cached = true;
+            }
+            __syncthreads();
+            if (cached && n_cache <= SEL_FIN_DIRECT) {
+                // a key per thread: the number of survivors with the same prefix below it (ties by index), by counting;
+                // the thread whose count equals a target's remaining rank holds that order statistic.  ~100 survivors
+                // when the bits are spread: cheaper than five more steps; a larger set goes on with the steps.
+                const uint32_t nc = n_cache;
+                const bool have = threadIdx.x < nc;
+                if (have) {
+                    const uint64_t mine = cache[threadIdx.x], mp = mine >> shift;
+                    uint32_t below = 0;
+                    for (uint32_t j = 0; j < nc; j++) {
+                        const uint64_t kj = cache[j];
+                        below += ((kj >> shift) == mp && (kj < mine || (kj == mine && j < threadIdx.x))) ? 1u : 0u;
+                    }
+#pragma unroll
+                    for (int t = 0; t < SEL_T; t++)
+                        if (mp == (st[2 * t] >> shift) && (uint64_t)below == st[2 * t + 1]) cache[SEL_FIN_CAP - 1 - t] = mine;
+                }
+                __syncthreads();
+                if (threadIdx.x < SEL_T) st[2 * threadIdx.x] = cache[SEL_FIN_CAP - 1 - threadIdx.x];
+                __syncthreads();
+                break;
+            }
+        }
+    }
+    if (threadIdx.x != 0) return;
+    double w[SEL_T];
+#pragma unroll
+    for (int t = 0; t < SEL_T; t++) { w[t] = value_of(st[2 * t]); v[t] = w[t]; }
+    const double median = (q.n % 2 != 0) ? w[1] : (w[0] + w[1]) / 2.0;
     // hf <= 0 / hf >= n only for n <= 2; the clamped ranks then already are min / max
     double q1, q3;
-    if (q.hf1 <= 0) q1 = v[3]; else if (q.hf1 >= (int64_t)q.n) q1 = v[2]; else q1 = v[2] + (q.h1 - (double)q.hf1) * (v[3] - v[2]);
-    if (q.hf3 <= 0) q3 = v[5]; else if (q.hf3 >= (int64_t)q.n) q3 = v[4]; else q3 = v[4] + (q.h3 - (double)q.hf3) * (v[5] - v[4]);
+    if (q.hf1 <= 0) q1 = w[3]; else if (q.hf1 >= (int64_t)q.n) q1 = w[2]; else q1 = w[2] + (q.h1 - (double)q.hf1) * (w[3] - w[2]);
+    if (q.hf3 <= 0) q3 = w[5]; else if (q.hf3 >= (int64_t)q.n) q3 = w[4]; else q3 = w[4] + (q.h3 - (double)q.hf3) * (w[5] - w[4]);
     const double iqr = q3 - q1;
     out[0] = median;
     out[1] = iqr;
     out[2] = q1 - q.iqr_multiple * iqr;  // main.rs:328-329
 }
 
-// The passes of the radix select for SEL_T 0-based ranks of n keys; the caller's final kernel runs the last step on
-// (*state_last, *hist_last).  No host synchronisation.
-static cellector_status select_passes(cellector_ctx *c, const double *keys, uint64_t n, const uint64_t ranks[SEL_T],
-                                      const uint64_t **state_last, const uint32_t **hist_last)
-{
-    if (n == 0) return ctx_fail(c, CELLECTOR_EINVAL, "order statistics of an empty array");
-    sel_ranks_t r;
-    for (int t = 0; t < SEL_T; t++) {
-        if (ranks[t] >= n) return ctx_fail(c, CELLECTOR_EINVAL, "rank %llu out of range", (unsigned long long)ranks[t]);
-        r.r[t] = ranks[t];
-    }
-    // pass p fills buffer p % 3 and clears buffer (p + 1) % 3; buffer 0 is cleared here for pass 0
-    uint32_t *hist[3] = {c->sel_hist, c->sel_hist + SEL_T * 256, c->sel_hist + 2 * SEL_T * 256};
-    uint64_t *state[2] = {c->sel_state, c->sel_state + 2 * SEL_T};
-    HIPCHK(c, hipMemsetAsync(hist[0], 0, SEL_T * 256 * sizeof(uint32_t), c->stream));
-    uint64_t g = (n + SEL_BLOCK * 4 - 1) / (SEL_BLOCK * 4);
-    if (g > 1024) g = 1024;
-    if (g < 1) g = 1;
-    for (int pass = 0; pass < SEL_PASSES; pass++)
-        hipLaunchKernelGGL(k_sel_pass, dim3((unsigned)g), dim3(SEL_BLOCK), 0, c->stream, keys, n, pass, r, state[(pass + 1) & 1],
-                           state[pass & 1], hist[(pass + 2) % 3], hist[pass % 3], hist[(pass + 1) % 3]);
-    *state_last = state[(SEL_PASSES - 1) & 1];
-    *hist_last = hist[(SEL_PASSES - 1) % 3];
-    HIPCHK(c, hipGetLastError());
-    return CELLECTOR_OK;
-}
-
 // median / quartiles / threshold of n keys into c->sel_out[8..10] = {median, iqr, threshold}, the six order statistics into
-// c->sel_out[0..5] (device memory)
+// c->sel_out[0..5] (device memory).  No host synchronisation.
 cellector_status select_threshold(cellector_ctx *c, const double *keys, uint64_t n, double iqr_multiple)
 {
+    if (n == 0) return ctx_fail(c, CELLECTOR_EINVAL, "order statistics of an empty array");
+    if (n > 0xffffffffull) return ctx_fail(c, CELLECTOR_EINVAL, "order statistics: more than 2^32 - 1 keys");
     // statrs Data::median / quantile: ranks of the order statistics needed
     const uint64_t k = n / 2;
     sel_quart_t q;
@@ -203,12 +495,27 @@ cellector_status select_threshold(cellector_ctx *c, const double *keys, uint64_t
     q.n = n;
     q.iqr_multiple = iqr_multiple;
     auto clampr = [n](int64_t r) -> uint64_t { return r < 0 ? 0 : ((uint64_t)r >= n ? n - 1 : (uint64_t)r); };
+    sel_ranks_t r;
     const uint64_t ranks[SEL_T] = {k ? k - 1 : 0, k, clampr(q.hf1 - 1), clampr(q.hf1), clampr(q.hf3 - 1), clampr(q.hf3)};
-    const uint64_t *state_last = nullptr;
-    const uint32_t *hist_last = nullptr;
+    for (int t = 0; t < SEL_T; t++) r.r[t] = ranks[t];
+    if (c->sel_list_cap < n) {
+        dev_free(c->sel_list);
+        c->sel_list = nullptr;
+        c->sel_list_cap = 0;
+        CHK(dev_alloc(c, &c->sel_list, n));
+        c->sel_list_cap = n;
+    }
+    uint32_t *hist0 = c->sel_hist, *hist1 = hist0 + SEL_NB0, *count = hist1 + SEL_T * SEL_NB1;
+    uint64_t *state1 = c->sel_state, *state2 = c->sel_state + 2 * SEL_T;
     timer_begin(c, CELLECTOR_K_SELECT);
-    CHK(select_passes(c, keys, n, ranks, &state_last, &hist_last));
-    hipLaunchKernelGGL(k_threshold, dim3(1), dim3(64), 0, c->stream, q, state_last, hist_last, c->sel_out, c->sel_out + 8);
+    uint64_t g = (n + SEL_THREADS * 4 - 1) / (SEL_THREADS * 4);
+    if (g > SEL_GRID) g = SEL_GRID;
+    hipLaunchKernelGGL(k_sel_top, dim3((unsigned)g), dim3(SEL_THREADS), 0, c->stream, keys, n, hist0);
+    hipLaunchKernelGGL(k_sel_mid, dim3((unsigned)g), dim3(SEL_THREADS), 0, c->stream, keys, n, r, hist0, state1, hist1);
+    hipLaunchKernelGGL(k_sel_gather, dim3((unsigned)g), dim3(SEL_THREADS), 0, c->stream, keys, n, state1, hist1, state2,
+                       c->sel_list, count);
+    hipLaunchKernelGGL(k_sel_finish, dim3(1), dim3(SEL_THREADS), 0, c->stream, q, state2, c->sel_list, count, hist0, c->sel_out,
+                       c->sel_out + 8);
     timer_end(c, CELLECTOR_K_SELECT);
     HIPCHK(c, hipGetLastError());
     return CELLECTOR_OK;

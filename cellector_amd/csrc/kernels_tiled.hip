@@ -81,16 +81,21 @@ struct ab_src_t {
     uint32_t *d_counters, *tile_work;
     uint32_t n_work;
 };
+// Six waves per 64 loci, each with its share of a locus' 18 values (about equal arithmetic): one thread per locus left
+// three waves per SIMD, too few to hide the dependent divisions and logs (75 us at 200k loci).
+#define TB_PARTS 6
 template <bool PAIRS>
-__global__ void k_build_tables(uint64_t L, uint32_t nj, const double2 *__restrict__ ab, const double *__restrict__ lf,
-                               double *__restrict__ tab, ab_src_t src)
+__global__ __launch_bounds__(64 * TB_PARTS) void k_build_tables(uint64_t L, uint32_t nj, const double2 *__restrict__ ab,
+                                                                const double *__restrict__ lf, double *__restrict__ tab,
+                                                                ab_src_t src)
 {
     if (src.s_alt && blockIdx.x == 0) {
         if (threadIdx.x < LC_COUNTERS) src.xl_counters[threadIdx.x] = 0.0;
         if (threadIdx.x < 8) src.d_counters[threadIdx.x] = 0u;
         for (uint32_t i = threadIdx.x; i < src.n_work; i += blockDim.x) src.tile_work[i] = 0u;
     }
-    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;  // (chunk, slot)
+    const int part = threadIdx.x >> 6;  // wave-uniform
+    const uint64_t t = (uint64_t)blockIdx.x * 64 + (threadIdx.x & 63);  // (chunk, slot)
     if (t >= (uint64_t)nj * T_BL) return;
     const uint64_t chunk = t / T_BL, slot = t % T_BL;
     const uint64_t l = chunk * T_BLU + slot;
@@ -100,17 +105,26 @@ __global__ void k_build_tables(uint64_t L, uint32_t nj, const double2 *__restric
             p.x = (src.s_alt[l] + 1.0) - src.alt_min[l];
             p.y = (src.s_ref[l] + 1.0) - src.ref_min[l];
             if (!src.mask[l]) p.x = p.y = -1.0;
-            src.ab_out[l] = p;
+            if (part == 0) src.ab_out[l] = p;
         } else {
             p = ab[l];
         }
     }
     const bool live = p.x >= 0.0;
     double *row = tab + chunk * TAB_ELEMS + slot * T_LROW;
-#pragma unroll
-    for (int w = 0; w < T_NCODE; w++) row[w] = live ? dm_log_bb_pmf(lf, p.x, p.y, T_A_OF[w], T_R_OF[w]) : 0.0;
-#pragma unroll
-    for (int n = 1; n <= T_K; n++) row[T_NCODE + n - 1] = (PAIRS && live) ? dm_expected_log_pmf(lf, p.x, p.y, (uint32_t)n) : 0.0;
+    // code w <-> (alt, ref) as in T_A_OF / T_R_OF, written out so that the products unroll
+#define TB_PMF(W, A, R) row[W] = live ? dm_log_bb_pmf(lf, p.x, p.y, A, R) : 0.0
+#define TB_EXP(N) row[T_NCODE + N - 1] = (PAIRS && live) ? dm_expected_log_pmf(lf, p.x, p.y, N) : 0.0
+    switch (part) {
+    case 0: TB_EXP(4u); TB_PMF(0, 1u, 0u); break;
+    case 1: TB_EXP(3u); TB_PMF(1, 0u, 1u); break;
+    case 2: TB_EXP(2u); TB_PMF(2, 2u, 0u); TB_PMF(3, 1u, 1u); break;
+    case 3: TB_EXP(1u); TB_PMF(4, 0u, 2u); TB_PMF(5, 3u, 0u); break;
+    case 4: TB_PMF(6, 2u, 1u); TB_PMF(7, 1u, 2u); TB_PMF(8, 0u, 3u); TB_PMF(9, 4u, 0u); break;
+    default: TB_PMF(10, 3u, 1u); TB_PMF(11, 2u, 2u); TB_PMF(12, 1u, 3u); TB_PMF(13, 0u, 4u); break;
+    }
+#undef TB_PMF
+#undef TB_EXP
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1592,7 +1606,7 @@ static cellector_status build_tile_tables(cellector_ctx *c, const double2 *ab, i
 {
     const uint64_t tab_elems = (uint64_t)c->t_nj * TAB_ELEMS;
     double *tab = expected ? c->tab + 3 * tab_elems : c->tab + (uint64_t)set * tab_elems;
-    const unsigned tgrid = gcap((uint64_t)c->t_nj * T_BL, 256);
+    const unsigned tgrid = gcap((uint64_t)c->t_nj * T_BL, 64);
     ab_src_t src = {};
     if (form_ab) {  // first kernel of an EM iteration: alpha/beta from the exchanged tallies, counters reset
         const uint64_t L = c->L;
@@ -1604,9 +1618,9 @@ static cellector_status build_tile_tables(cellector_ctx *c, const double2 *ab, i
         c->work_zeroed = true;
     }
     if (expected)
-        hipLaunchKernelGGL(k_build_tables<true>, dim3(tgrid), dim3(256), 0, c->stream, c->L, c->t_nj, ab, c->lf, tab, src);
+        hipLaunchKernelGGL(k_build_tables<true>, dim3(tgrid), dim3(64 * TB_PARTS), 0, c->stream, c->L, c->t_nj, ab, c->lf, tab, src);
     else
-        hipLaunchKernelGGL(k_build_tables<false>, dim3(tgrid), dim3(256), 0, c->stream, c->L, c->t_nj, ab, c->lf, tab, src);
+        hipLaunchKernelGGL(k_build_tables<false>, dim3(tgrid), dim3(64 * TB_PARTS), 0, c->stream, c->L, c->t_nj, ab, c->lf, tab, src);
     if (set == 0) {  // the locus pass of this iteration reads the log-pmfs of the EM pass' table
         c->tab_em = tab;
         c->tab_em_stride = expected ? 2 : 1;
@@ -1664,15 +1678,19 @@ cellector_status tiled_cell_pass(cellector_ctx *c, const double2 *ab, double *no
     if (for_em && c->tables_prebuilt) c->tables_prebuilt = false;  // built ahead by the previous iteration's em_finish
     else CHK(build_tile_tables(c, ab, 0, c->compute_expected, for_em));
     if (ovf && c->overlap) {
+        // the tile kernel is launched FIRST: with the tables built ahead the queue is empty when the host gets here, and
+        // every launch ahead of it (five on the side stream) would be ~10 us of idle GPU
         CHK(side_fork(c));
+        CHK(run_tile_pass(c, 0, c->compute_expected));
         launch_overflow_cell(c, c->side, ab, 0, c->compute_expected);
         HIPCHK(c, hipEventRecord(c->ev_join, c->side));
-        if (for_em && c->overlap == 1) {  // the locus side's values right behind the cell side, beside the tile kernel
-            launch_overflow_locus_values(c, c->side, ab);
+        bool joined2 = false;
+        if (for_em && c->overlap == 1) {  // the locus side's values right behind the cell side, beside the tile kernel:
+            launch_overflow_locus_values(c, c->side, ab);  // one join for both (every cross-stream wait idles the queue ~6 us)
             HIPCHK(c, hipEventRecord(c->ev_join2, c->side));
-            c->ovf_locus_pending = true;
+            HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join2, 0));
+            joined2 = true;
         }
-        CHK(run_tile_pass(c, 0, c->compute_expected));
         if (for_em && c->overlap == 2) {  // ... or once the tile kernel is done, beside the order statistics
             HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
             HIPCHK(c, hipStreamWaitEvent(c->side, c->ev_fork, 0));
@@ -1680,7 +1698,7 @@ cellector_status tiled_cell_pass(cellector_ctx *c, const double2 *ab, double *no
             HIPCHK(c, hipEventRecord(c->ev_join2, c->side));
             c->ovf_locus_pending = true;
         }
-        HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
+        if (!joined2) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
     } else {
         if (ovf) {
             launch_overflow_cell(c, c->stream, ab, 0, c->compute_expected);

@@ -413,6 +413,52 @@ def test_two_shards_equal_single_shard(mods):
         s.close()
 
 
+def test_order_statistics_on_adversarial_keys(mods):
+    """The device order statistics (csrc/kernels_select.hip) against the oracle's restatement of statrs Data::median /
+    quantile on keys no EM run produces: the NORM exchange buffer is overwritten between em_begin and em_threshold, the
+    summary's median / iqr / threshold must be bit-identical (ties, one shared 22-bit prefix, huge range, signs, tiny n)."""
+    if mods["engine"] != 2:
+        pytest.skip("one select implementation; run once")
+    hip, ob, ffi = _hip(), mods["ob"], mods["ffi"]
+    rng = np.random.default_rng(7)
+    cases = [
+        (1, lambda n: np.array([-0.25])),
+        (2, lambda n: np.array([3.0, -1.0])),
+        (3, lambda n: np.array([0.0, -0.0, -1e-310])),
+        (4, lambda n: np.array([-1.0, -1.0, -1.0, -2.0])),
+        (5000, lambda n: np.full(n, -0.5)),                                      # every key in every step's one bin
+        (5000, lambda n: np.where(rng.random(n) < 0.5, -0.5, -0.75)),            # two heavy ties
+        (40000, lambda n: -0.5 - np.arange(n) * 1e-13),                          # one 22-bit prefix, all distinct
+        (40000, lambda n: -rng.uniform(0.25, 1.0, n)),
+        (40000, lambda n: rng.standard_normal(n) * 10.0 ** rng.integers(-300, 300, n)),   # every exponent, both signs
+        (40000, lambda n: np.round(rng.standard_normal(n), 1)),                  # ~80 distinct values
+        (300000, lambda n: -np.exp(rng.standard_normal(n) * 0.2) * 0.5),
+        (300001, lambda n: np.concatenate([np.zeros(n // 3), -rng.uniform(0.4, 0.6, n - n // 3)])),
+    ]
+    for n, make in cases:
+        L = 40
+        lo, ce, al, re = mods["synth"].generate_coo(L, n, 0.3 if n < 100000 else 0.05, seed=11)
+        if len(lo) == 0:
+            lo, ce = np.zeros(1, np.uint32), np.zeros(1, np.uint32)
+            al, re = np.ones(1, np.uint32), np.ones(1, np.uint32)
+        g = mods["Cellector"](0)
+        g.load_coo(L, n, lo, ce, al, re, 0, 0)
+        g.em_begin()
+        ptr, m = g.exchange_buffer(ffi.XCHG_NORM)
+        assert m >= n
+        keys = np.ascontiguousarray(make(n), dtype=np.float64)
+        assert len(keys) == n and not np.isnan(keys).any()
+        assert hip.hipMemcpy(ptr, keys.ctypes.data, n * 8, 1) == 0
+        g.em_threshold(5.0)
+        s = g.em_finish()
+        q1, q3 = ob.quantile(keys, 0.25), ob.quantile(keys, 0.75)
+        assert s.median == ob.median(keys), n
+        assert s.iqr == q3 - q1, n
+        assert s.threshold == q1 - 5.0 * (q3 - q1), n
+        assert s.n_excluded == int((keys < s.threshold).sum()), n
+        g.close()
+
+
 def test_medium_matrix_properties_and_parity(mods):
     """20k cells x 20k loci at 1% (device-generated, ~4e6 entries): oracle parity for the first iteration and
     the size-independent properties the path offers."""
