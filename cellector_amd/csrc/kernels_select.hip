@@ -9,8 +9,8 @@
 //                 keys that carry a target's 12-bit prefix (targets that share a prefix share a histogram);
 //   k_sel_gather  the step on those histograms, then the keys that carry a target's 22-bit prefix are appended to a list
 //                 (N / 2000 of them per target when the mantissa bits are spread; all of them in the worst case);
-//   k_sel_finish  one workgroup: the remaining 42 bits, 7 per step, over the list, then the quartile / threshold
-//                 arithmetic.
+//   k_sel_finish  one workgroup: the remaining 42 bits over the list (11 bits, then the few survivors ranked by
+//                 counting), then the quartile / threshold arithmetic.
 // Few workgroups on purpose (SEL_GRID): a workgroup's histogram goes to the global one with one atomic per non-empty
 // bin, and atomics to the same few cache lines run one after the other — 1024 workgroups x 256 bins took 40 us.
 // The results stay in device memory: the flagging kernel reads the threshold there.  The histograms are zero when a
@@ -23,8 +23,6 @@
 #define SEL_NB1 1024  // bins of bits 51..42
 #define SEL_SH0 52
 #define SEL_SH1 42
-#define SEL_FIN_BITS 7
-#define SEL_FIN_STEPS 6  // 6 x 7 = the 42 low bits
 
 __device__ __forceinline__ uint64_t key_of(double x)
 {
@@ -61,7 +59,8 @@ __device__ __forceinline__ void sel_scan(int lane, const uint32_t *hist, uint64_
     }
     inc = v;
 }
-// ... and the bin that holds 0-based rank r, with the number of keys below that bin (valid in every lane)
+// ... and the bin that holds 0-based rank r, with the number of keys below that bin (valid in every lane).  Up to 32 bins
+// per lane are fetched together and walked in registers instead of one dependent load per bin.
 template <int NB>
 __device__ __forceinline__ void sel_pick(int lane, const uint32_t *hist, uint64_t lsum, uint64_t inc, uint64_t r, uint32_t &bin,
                                          uint64_t &below)
@@ -70,10 +69,23 @@ __device__ __forceinline__ void sel_pick(int lane, const uint32_t *hist, uint64_
     const uint64_t exc = inc - lsum;
     // the lane whose bins contain the rank (the last lane if counts are short: defensive, cannot happen)
     const bool mine = (exc <= r && r < inc) || (lane == 63 && r >= inc);
-    uint32_t d = 0;
+    uint32_t d = (uint32_t)(lane * PER);
     uint64_t cum = exc;
-    if (mine) {
-        d = (uint32_t)(lane * PER);
+    if constexpr (PER <= 32) {
+        uint32_t hs[PER];
+        const uint4 *src4 = reinterpret_cast<const uint4 *>(hist + lane * PER);
+#pragma unroll
+        for (int i = 0; i < PER / 4; i++) {
+            const uint4 q = src4[i];
+            hs[4 * i] = q.x; hs[4 * i + 1] = q.y; hs[4 * i + 2] = q.z; hs[4 * i + 3] = q.w;
+        }
+        bool go = mine;
+#pragma unroll
+        for (int i = 0; i < PER - 1; i++) {
+            go = go && cum + hs[i] <= r;
+            if (go) { cum += hs[i]; d++; }
+        }
+    } else if (mine) {  // (64 bins in registers for six targets spill: the one lane walks memory)
         for (int i = 0; i < PER - 1; i++) {
             const uint32_t h = hist[lane * PER + i];
             if (cum + h > r) break;
@@ -282,15 +294,18 @@ __global__ __launch_bounds__(SEL_THREADS) void k_sel_gather(const double *__rest
 struct sel_quart_t { double h1, h3; int64_t hf1, hf3; uint64_t n; double iqr_multiple; };
 
 // one workgroup: the low 42 bits over the gathered keys (the six order statistics -> v[0..5]), then the threshold
-// arithmetic -> out[0..2].  After the first step the keys that still carry a target's prefix (1/128 of the list when the
-// bits are spread) move to LDS and the later steps run there; ties that do not fit stay in the global list.
-#define SEL_FIN_CAP 4096
-#define SEL_FIN_DIRECT 256  // survivors ranked by counting instead of further steps
-__device__ __forceinline__ void sel_fin_vote(uint64_t k, int shift, const uint64_t hi[SEL_T], const bool lead[SEL_T],
-                                             uint32_t (*h)[1 << SEL_FIN_BITS])
+// arithmetic -> out[0..2].  The first step takes 11 bits (2048-bin histograms): of ~10^4 gathered keys a handful per
+// target survive it, they move to LDS and are ranked by counting.  Keys that do not spread (ties) go on in 7-bit steps,
+// from LDS when they fit, from the list otherwise.
+#define SEL_FIN_CAP 1024     // survivors kept in LDS
+#define SEL_FIN_DIRECT 256   // ... and ranked by counting instead of further steps
+#define SEL_FIN_NB 2048      // bins of the first step
+#define SEL_FIN_STEPS 6      // bits 41..31, then 7, 7, 7, 7, 3
+__device__ __forceinline__ void sel_fin_vote(uint64_t k, int shift, int bits, const uint64_t hi[SEL_T], const bool lead[SEL_T],
+                                             uint32_t (*h)[SEL_FIN_NB])
 {
-    const uint32_t d = (uint32_t)(k >> shift) & ((1u << SEL_FIN_BITS) - 1u);
-    const uint64_t kh = k >> (shift + SEL_FIN_BITS);
+    const uint32_t d = (uint32_t)(k >> shift) & ((1u << bits) - 1u);
+    const uint64_t kh = k >> (shift + bits);
 #pragma unroll
     for (int t = 0; t < SEL_T; t++)
         if (lead[t] && kh == hi[t]) atomicAdd(&h[t][d], 1u);
@@ -300,12 +315,10 @@ __global__ __launch_bounds__(SEL_THREADS) void k_sel_finish(sel_quart_t q, const
                                                             uint32_t *scratch /* holds *count */, double *__restrict__ v,
                                                             double *__restrict__ out)
 {
-    constexpr int NB = 1 << SEL_FIN_BITS;
-    static_assert(NB == 128, "a lane owns two bins in the step below");
-    __shared__ uint32_t h[SEL_T][NB];
+    __shared__ uint32_t h[SEL_T][SEL_FIN_NB];
     __shared__ uint64_t st[2 * SEL_T];
     __shared__ int leader[SEL_T];
-    __shared__ uint64_t cache[SEL_FIN_CAP];
+    __shared__ uint64_t cache[SEL_FIN_CAP + SEL_T];  // (+ the direct ranking's results)
     __shared__ uint32_t n_cache;
     const uint32_t m = *count;
     // the histograms and the list length are zero again for the next call (the earlier kernels are done with them: this
@@ -327,9 +340,12 @@ __global__ __launch_bounds__(SEL_THREADS) void k_sel_finish(sel_quart_t q, const
     }
     if (threadIdx.x < 2 * SEL_T) st[threadIdx.x] = state2[threadIdx.x];
     __syncthreads();
+    int top = SEL_SH1;  // bits [top, 64) are resolved
     for (int step = 0; step < SEL_FIN_STEPS; step++) {
-        const int shift = SEL_SH1 - SEL_FIN_BITS * (step + 1);
-        for (int i = threadIdx.x; i < SEL_T * NB; i += SEL_THREADS) (&h[0][0])[i] = 0;
+        const int bits = step == 0 ? 11 : (top >= 7 ? 7 : top);
+        const int shift = top - bits;
+        const int nbs = step == 0 ? 11 : 8;  // log2 of the bins zeroed and scanned (a later step's digits stay below 128)
+        for (int i = threadIdx.x; i < (SEL_T << nbs); i += SEL_THREADS) h[i >> nbs][i & ((1 << nbs) - 1)] = 0;
         if (threadIdx.x == 0) {
             uint64_t p[SEL_T];
             int ld[SEL_T];
@@ -343,14 +359,14 @@ __global__ __launch_bounds__(SEL_THREADS) void k_sel_finish(sel_quart_t q, const
         uint64_t hi[SEL_T];
         bool lead[SEL_T];
 #pragma unroll
-        for (int t = 0; t < SEL_T; t++) { hi[t] = st[2 * t] >> (shift + SEL_FIN_BITS); lead[t] = leader[t] == t; }
+        for (int t = 0; t < SEL_T; t++) { hi[t] = st[2 * t] >> top; lead[t] = leader[t] == t; }
         if (cached) {
             const uint32_t nc = n_cache;
-            for (uint32_t i = threadIdx.x; i < nc; i += SEL_THREADS) sel_fin_vote(cache[i], shift, hi, lead, h);
+            for (uint32_t i = threadIdx.x; i < nc; i += SEL_THREADS) sel_fin_vote(cache[i], shift, bits, hi, lead, h);
         } else if (in_regs) {
 #pragma unroll
             for (int u = 0; u < FIN_REG; u++)
-                if (u * SEL_THREADS + threadIdx.x < m) sel_fin_vote(kr[u], shift, hi, lead, h);
+                if (u * SEL_THREADS + threadIdx.x < m) sel_fin_vote(kr[u], shift, bits, hi, lead, h);
         } else {
             for (uint32_t i0 = 0; i0 < m; i0 += 4 * SEL_THREADS) {  // four loads in flight
                 uint64_t k[4];
@@ -361,37 +377,29 @@ __global__ __launch_bounds__(SEL_THREADS) void k_sel_finish(sel_quart_t q, const
                 }
 #pragma unroll
                 for (int u = 0; u < 4; u++)
-                    if (i0 + u * SEL_THREADS + threadIdx.x < m) sel_fin_vote(k[u], shift, hi, lead, h);
+                    if (i0 + u * SEL_THREADS + threadIdx.x < m) sel_fin_vote(k[u], shift, bits, hi, lead, h);
             }
         }
         __syncthreads();
         if (threadIdx.x == 0 && !cached) n_cache = 0;
-        if (threadIdx.x < 64) {  // lane owns bins 2 lane, 2 lane + 1
+        if (threadIdx.x < 64) {
             const int lane = (int)threadIdx.x;
             uint64_t np[SEL_T], nr[SEL_T];
 #pragma unroll
             for (int t = 0; t < SEL_T; t++) {
                 const uint32_t *hist = &h[leader[t]][0];
                 const uint64_t r = st[2 * t + 1];
-                const uint32_t h0 = hist[2 * lane], h1 = hist[2 * lane + 1];
-                const uint64_t lsum = (uint64_t)h0 + h1;
-                uint64_t inc = lsum;
-#pragma unroll
-                for (int off = 1; off < 64; off <<= 1) {
-                    const uint64_t o = (uint64_t)__shfl_up((long long)inc, off, 64);
-                    if (lane >= off) inc += o;
+                uint64_t lsum, inc, below;
+                uint32_t bin;
+                if (step == 0) {
+                    sel_scan<SEL_FIN_NB>(lane, hist, lsum, inc);
+                    sel_pick<SEL_FIN_NB>(lane, hist, lsum, inc, r, bin, below);
+                } else {
+                    sel_scan<256>(lane, hist, lsum, inc);
+                    sel_pick<256>(lane, hist, lsum, inc, r, bin, below);
                 }
-                const uint64_t exc = inc - lsum;
-                const bool mine = (exc <= r && r < inc) || (lane == 63 && r >= inc);
-                const bool second = mine && exc + h0 <= r;
-                const uint32_t d = (uint32_t)(2 * lane + (second ? 1 : 0));
-                const uint64_t cum = exc + (second ? h0 : 0);
-                const unsigned long long who = __ballot(mine);
-                const int src = __ffsll((long long)who) - 1;
-                const uint32_t dsel = (uint32_t)__shfl((int)d, src, 64);
-                const uint64_t csel = (uint64_t)__shfl((long long)cum, src, 64);
-                np[t] = st[2 * t] | ((uint64_t)dsel << shift);
-                nr[t] = r - csel;
+                np[t] = st[2 * t] | ((uint64_t)bin << shift);
+                nr[t] = r - below;
             }
             if (lane == 0) {
 #pragma unroll
@@ -399,13 +407,15 @@ __global__ __launch_bounds__(SEL_THREADS) void k_sel_finish(sel_quart_t q, const
             }
         }
         __syncthreads();
-        if (!cached && step + 1 < SEL_FIN_STEPS) {
+        top = shift;
+        if (top == 0) break;
+        if (!cached) {
             // the survivors of this step: how many is known from the histograms, so the decision is uniform
             uint64_t keep = 0;
 #pragma unroll
             for (int t = 0; t < SEL_T; t++)
                 if (leader[t] == t || (st[2 * t] != st[2 * leader[t]]))  // one count per distinct new prefix
-                    keep += h[leader[t]][(uint32_t)(st[2 * t] >> shift) & (NB - 1)];
+                    keep += h[leader[t]][(uint32_t)(st[2 * t] >> shift) & ((1u << bits) - 1u)];
             // (targets that shared a histogram and still share the prefix were counted once; targets that split were
             //  counted each: keep >= the number of distinct survivors)
             if (keep <= SEL_FIN_CAP) {
@@ -440,28 +450,26 @@ __global__ __launch_bounds__(SEL_THREADS) void k_sel_finish(sel_quart_t q, const
                 cached = true;
             }
             __syncthreads();
-            if (cached && n_cache <= SEL_FIN_DIRECT) {
-                // a key per thread: the number of survivors with the same prefix below it (ties by index), by counting;
-                // the thread whose count equals a target's remaining rank holds that order statistic.  ~100 survivors
-                // when the bits are spread: cheaper than five more steps; a larger set goes on with the steps.
-                const uint32_t nc = n_cache;
-                const bool have = threadIdx.x < nc;
-                if (have) {
-                    const uint64_t mine = cache[threadIdx.x], mp = mine >> shift;
-                    uint32_t below = 0;
-                    for (uint32_t j = 0; j < nc; j++) {
-                        const uint64_t kj = cache[j];
-                        below += ((kj >> shift) == mp && (kj < mine || (kj == mine && j < threadIdx.x))) ? 1u : 0u;
-                    }
-#pragma unroll
-                    for (int t = 0; t < SEL_T; t++)
-                        if (mp == (st[2 * t] >> shift) && (uint64_t)below == st[2 * t + 1]) cache[SEL_FIN_CAP - 1 - t] = mine;
+        }
+        if (cached && n_cache <= SEL_FIN_DIRECT) {
+            // a key per thread: the number of survivors with the same prefix below it (ties by index), by counting; the
+            // thread whose count equals a target's remaining rank holds that order statistic
+            const uint32_t nc = n_cache;
+            if (threadIdx.x < nc) {
+                const uint64_t mine = cache[threadIdx.x], mp = mine >> shift;
+                uint32_t below = 0;
+                for (uint32_t j = 0; j < nc; j++) {
+                    const uint64_t kj = cache[j];
+                    below += ((kj >> shift) == mp && (kj < mine || (kj == mine && j < threadIdx.x))) ? 1u : 0u;
                 }
-                __syncthreads();
-                if (threadIdx.x < SEL_T) st[2 * threadIdx.x] = cache[SEL_FIN_CAP - 1 - threadIdx.x];
-                __syncthreads();
-                break;
+#pragma unroll
+                for (int t = 0; t < SEL_T; t++)
+                    if (mp == (st[2 * t] >> shift) && (uint64_t)below == st[2 * t + 1]) cache[SEL_FIN_CAP + t] = mine;
             }
+            __syncthreads();
+            if (threadIdx.x < SEL_T) st[2 * threadIdx.x] = cache[SEL_FIN_CAP + threadIdx.x];
+            __syncthreads();
+            break;
         }
     }
     if (threadIdx.x != 0) return;

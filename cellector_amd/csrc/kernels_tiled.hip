@@ -629,7 +629,8 @@ __global__ __launch_bounds__(256) void k_ovf_cell_listed(uint64_t n_list, const 
     if (EXPECTED) o_ell[row] += e;
 }
 
-// chunk-group partials in group order, then the row's overflow sum, then the normalisation (main.rs:314-323)
+// chunk-group partials in group order, then the row's overflow sum, then the normalisation (main.rs:314-323).
+// Two rows per thread: 16-byte loads and stores (8-byte ones left this 190 MB stream at 1.8 TB/s).
 template <bool EXPECTED>
 __global__ __launch_bounds__(256) void k_cell_finalize(uint64_t n_rows, uint32_t groups, uint64_t npad,
                                                        const double *__restrict__ part_ll,
@@ -641,22 +642,52 @@ __global__ __launch_bounds__(256) void k_cell_finalize(uint64_t n_rows, uint32_t
                                                        double *__restrict__ ell, double *__restrict__ nloci,
                                                        double *__restrict__ norm_out)
 {
-    const uint64_t row = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t row = 2 * ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x);
     if (row >= n_rows) return;
-    double s = 0.0, e = 0.0;
-    for (uint32_t g = 0; g < groups; g++) {
-        s += part_ll[(uint64_t)g * npad + row];
-        if (EXPECTED) e += part_ell[(uint64_t)g * npad + row];
+    const bool two = row + 1 < n_rows;  // (npad is even and the arrays are 16-byte aligned: a pair never straddles)
+    double2 s = make_double2(0.0, 0.0), e = make_double2(0.0, 0.0);
+    for (uint32_t g0 = 0; g0 < groups; g0 += 8) {  // eight groups' partials in flight, added in group order
+        double2 pl[8], pe[8];
+#pragma unroll
+        for (uint32_t u = 0; u < 8; u++) {
+            const bool ok = g0 + u < groups;
+            pl[u] = ok ? *reinterpret_cast<const double2 *>(part_ll + (uint64_t)(g0 + u) * npad + row) : make_double2(0.0, 0.0);
+            if (EXPECTED)
+                pe[u] = ok ? *reinterpret_cast<const double2 *>(part_ell + (uint64_t)(g0 + u) * npad + row) : make_double2(0.0, 0.0);
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < 8; u++) {
+            if (g0 + u < groups) {
+                s.x += pl[u].x; s.y += pl[u].y;
+                if (EXPECTED) { e.x += pe[u].x; e.y += pe[u].y; }
+            }
+        }
     }
     if (o_ll) {
-        s += o_ll[row];
-        if (EXPECTED) e += o_ell[row];
+        s.x += o_ll[row];
+        if (two) s.y += o_ll[row + 1];
+        if (EXPECTED) {
+            e.x += o_ell[row];
+            if (two) e.y += o_ell[row + 1];
+        }
     }
-    const double cnt = (double)((csr_ptr[row + 1] - csr_ptr[row]) - (uint64_t)masked_cnt[row]);
-    ll[row] = s;
-    if (EXPECTED) ell[row] = e;
-    nloci[row] = cnt;
-    if (norm_out) norm_out[row] = cnt > 0.0 ? s / cnt : 0.0;  // main.rs:315-322
+    const uint64_t p0 = csr_ptr[row], p1 = csr_ptr[row + 1], p2 = two ? csr_ptr[row + 2] : p1;
+    const double c0 = (double)((p1 - p0) - (uint64_t)masked_cnt[row]);
+    const double c1 = two ? (double)((p2 - p1) - (uint64_t)masked_cnt[row + 1]) : 0.0;
+    const double n0 = c0 > 0.0 ? s.x / c0 : 0.0, n1 = c1 > 0.0 ? s.y / c1 : 0.0;  // main.rs:315-322
+    if (two) {
+        *reinterpret_cast<double2 *>(ll + row) = s;
+        if (EXPECTED) *reinterpret_cast<double2 *>(ell + row) = e;
+        *reinterpret_cast<double2 *>(nloci + row) = make_double2(c0, c1);
+    } else {
+        ll[row] = s.x; nloci[row] = c0;
+        if (EXPECTED) ell[row] = e.x;
+        if (two) { ll[row + 1] = s.y; nloci[row + 1] = c1; if (EXPECTED) ell[row + 1] = e.y; }
+    }
+    if (norm_out) {  // a slice of the exchange buffer: starts at the shard's first cell, any parity
+        norm_out[row] = n0;
+        if (two) norm_out[row + 1] = n1;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1684,12 +1715,10 @@ cellector_status tiled_cell_pass(cellector_ctx *c, const double2 *ab, double *no
         CHK(run_tile_pass(c, 0, c->compute_expected));
         launch_overflow_cell(c, c->side, ab, 0, c->compute_expected);
         HIPCHK(c, hipEventRecord(c->ev_join, c->side));
-        bool joined2 = false;
-        if (for_em && c->overlap == 1) {  // the locus side's values right behind the cell side, beside the tile kernel:
-            launch_overflow_locus_values(c, c->side, ab);  // one join for both (every cross-stream wait idles the queue ~6 us)
+        if (for_em && c->overlap == 1) {  // the locus side's values right behind the cell side, beside the tile kernel
+            launch_overflow_locus_values(c, c->side, ab);  // (they may end after it: only the locus finalize waits for them)
             HIPCHK(c, hipEventRecord(c->ev_join2, c->side));
-            HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join2, 0));
-            joined2 = true;
+            c->ovf_locus_pending = true;
         }
         if (for_em && c->overlap == 2) {  // ... or once the tile kernel is done, beside the order statistics
             HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
@@ -1698,7 +1727,7 @@ cellector_status tiled_cell_pass(cellector_ctx *c, const double2 *ab, double *no
             HIPCHK(c, hipEventRecord(c->ev_join2, c->side));
             c->ovf_locus_pending = true;
         }
-        if (!joined2) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
+        HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
     } else {
         if (ovf) {
             launch_overflow_cell(c, c->stream, ab, 0, c->compute_expected);
@@ -1708,7 +1737,7 @@ cellector_status tiled_cell_pass(cellector_ctx *c, const double2 *ab, double *no
     }
     double *part_ll = c->part, *part_ell = c->part + (uint64_t)c->t_groups * c->t_npad;
     const double *o_ll = ovf ? c->ovf_sum : nullptr, *o_ell = ovf ? c->ovf_sum + c->nloc : nullptr;
-    const unsigned grid = gcap(c->nloc, 256, 0x7fffffffu);
+    const unsigned grid = gcap((c->nloc + 1) / 2, 256, 0x7fffffffu);
     if (c->compute_expected)
         hipLaunchKernelGGL(k_cell_finalize<true>, dim3(grid), dim3(256), 0, c->stream, c->nloc, c->t_groups, c->t_npad, part_ll,
                            part_ell, o_ll, o_ell, c->csr_ptr, c->masked_cnt, c->ll, c->ell, c->nloci, norm_out);
@@ -1724,6 +1753,9 @@ cellector_status tiled_locus_pass(cellector_ctx *c)
 {
     if (c->L == 0) return CELLECTOR_OK;
     timer_begin(c, CELLECTOR_K_LOCUS_STATS);
+    // (k_locus_finalize's loop over the overflow entries, a third of its time at 10^6 cells, was tried as a kernel of its
+    //  own on the side stream beside k_minority_ranges: both stream scattered lines, the pair took as long as one after
+    //  the other)
     const uint32_t words = (uint32_t)((c->nloc + 31) / 32);
     // (k_flag wrote the exclusion bitmask flag_bits along with the flags)
     const size_t lds = (size_t)words * 4;

@@ -62,7 +62,8 @@ cellector_status cellector_set_stream(cellector_ctx *ctx, void *hip_stream);
  * 1 = stream the whole compact CSC past the exclusion bitmask; bit-identical results),
  * "overlap" (engine 2, default 1: the kernels of the few entries with alt+ref = 0 or > 4 run on a side
  * stream beside the table-lookup kernel; 2 = their locus-side part only after that kernel; 0 = everything
- * in one stream; same results to the bit). */
+ * in one stream; same results to the bit),
+ * "side_lds" (engine 2, default -1: automatic residency throttle of the side-stream kernels). */
 cellector_status cellector_set_option(cellector_ctx *ctx, const char *key, int64_t value);
 
 /* ---- sharding (before ingest) --------------------------------------------------------------- */

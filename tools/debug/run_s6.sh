@@ -1,14 +1,14 @@
 export TMPDIR=/tmp
-out=gpurun_out/s5f; mkdir -p $out
+out=gpurun_out/$1; mkdir -p $out
 timeout -k 10 900 python -m pytest tests -m gpu -x -q > $out/pytest_gpu.log 2>&1; rc=$?
-echo pytest=$rc; tail -5 $out/pytest_gpu.log
+echo pytest=$rc; tail -3 $out/pytest_gpu.log
 [ $rc -eq 0 ] || exit $rc
-timeout -k 10 300 python3 tools/fuzz_parity.py --cases 40 --seed 51 > $out/fuzz.log 2>&1 || { tail -5 $out/fuzz.log; exit 1; }
-tail -1 $out/fuzz.log
-timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $out/trace -- python3 tools/shard_rehearsal.py --ranks 8 --steps 4 --warmup 2 > $out/run.log 2>&1 || { tail -5 $out/run.log; exit 1; }
-f=$(ls $out/trace/*/*_kernel_trace.csv | head -1)
-python3 tools/timeline.py $f 40 > $out/timeline.txt
-rm -rf $out/trace
+for R in 1 8; do
+timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $out/trace$R -- python3 tools/shard_rehearsal.py --ranks $R --steps 4 --warmup 2 > $out/run$R.log 2>&1 || { tail -5 $out/run$R.log; exit 1; }
+f=$(ls $out/trace$R/*/*_kernel_trace.csv | head -1)
+python3 tools/timeline.py $f 40 > $out/timeline$R.txt
+rm -rf $out/trace$R
+done
 timeout -k 10 600 python3 bench.py --no-cpu-baseline > $out/bench.json 2> $out/bench.err || { tail -5 $out/bench.err; exit 1; }
 python3 -c "
 import json; d=json.load(open('$out/bench.json')); print('ms', d['ms_per_step'], d['kernels_ms'], 'frac', d['roofline']['frac'], 'launch', d['roofline']['launch_ms'])"
