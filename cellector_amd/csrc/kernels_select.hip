@@ -19,6 +19,8 @@
 
 #define SEL_THREADS 1024
 #define SEL_GRID 128
+#define SEL_UNROLL 8  // keys per thread in flight (10^6 keys: one round)
+#define SEL_GATHER_ROUND 4  // ... in the gathering pass: a round's matches wait in 32 KB of LDS
 #define SEL_NB0 4096  // bins of bits 63..52
 #define SEL_NB1 1024  // bins of bits 51..42
 #define SEL_SH0 52
@@ -119,17 +121,17 @@ __global__ __launch_bounds__(SEL_THREADS) void k_sel_top(const double *__restric
     __syncthreads();
     const int lane = threadIdx.x & 63;
     const uint64_t stride = (uint64_t)gridDim.x * SEL_THREADS;
-    for (uint64_t base = (uint64_t)blockIdx.x * SEL_THREADS; base < n; base += 4 * stride) {
-        uint64_t k[4];
-        bool ok[4];
+    for (uint64_t base = (uint64_t)blockIdx.x * SEL_THREADS; base < n; base += SEL_UNROLL * stride) {
+        uint64_t k[SEL_UNROLL];
+        bool ok[SEL_UNROLL];
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
+        for (int u = 0; u < SEL_UNROLL; u++) {
             const uint64_t i = base + u * stride + threadIdx.x;
             ok[u] = i < n;
             k[u] = ok[u] ? key_of(keys[i]) : 0;
         }
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
+        for (int u = 0; u < SEL_UNROLL; u++) {
             const uint32_t d = (uint32_t)(k[u] >> SEL_SH0);
             const unsigned long long act = __ballot(ok[u]);
             if (!act) continue;  // wave-uniform
@@ -157,48 +159,42 @@ __global__ __launch_bounds__(SEL_THREADS) void k_sel_mid(const double *__restric
 {
     __shared__ uint32_t h[SEL_T][SEL_NB1];
     __shared__ uint32_t top[SEL_T];
-    __shared__ int leader[SEL_T];
     for (int i = threadIdx.x; i < SEL_T * SEL_NB1; i += SEL_THREADS) (&h[0][0])[i] = 0;
-    if (threadIdx.x < 64) {
-        const int lane = (int)threadIdx.x;
-        uint64_t lsum, inc, np[SEL_T], nr[SEL_T];
+    if (threadIdx.x < 64 * SEL_T) {  // a wave per target: the step is on every workgroup's critical path
+        const int lane = (int)threadIdx.x & 63, t = (int)threadIdx.x >> 6;
+        uint64_t lsum, inc, below;
+        uint32_t bin;
         sel_scan<SEL_NB0>(lane, hist0, lsum, inc);
-#pragma unroll
-        for (int t = 0; t < SEL_T; t++) {
-            uint32_t bin;
-            uint64_t below;
-            sel_pick<SEL_NB0>(lane, hist0, lsum, inc, ranks.r[t], bin, below);
-            np[t] = (uint64_t)bin << SEL_SH0;
-            nr[t] = ranks.r[t] - below;
-        }
+        sel_pick<SEL_NB0>(lane, hist0, lsum, inc, ranks.r[t], bin, below);
         if (lane == 0) {
-            int ld[SEL_T];
-            sel_leaders(np, ld);
-#pragma unroll
-            for (int t = 0; t < SEL_T; t++) {
-                top[t] = (uint32_t)(np[t] >> SEL_SH0);
-                leader[t] = ld[t];
-                if (blockIdx.x == 0) { state1[2 * t] = np[t]; state1[2 * t + 1] = nr[t]; }
-            }
+            top[t] = bin;
+            if (blockIdx.x == 0) { state1[2 * t] = (uint64_t)bin << SEL_SH0; state1[2 * t + 1] = ranks.r[t] - below; }
         }
     }
     __syncthreads();
     uint32_t ltop[SEL_T];
     bool lead[SEL_T];
+    {
+        uint64_t p[SEL_T];
+        int ld[SEL_T];
 #pragma unroll
-    for (int t = 0; t < SEL_T; t++) { ltop[t] = top[t]; lead[t] = leader[t] == t; }
+        for (int t = 0; t < SEL_T; t++) { ltop[t] = top[t]; p[t] = ltop[t]; }
+        sel_leaders(p, ld);
+#pragma unroll
+        for (int t = 0; t < SEL_T; t++) lead[t] = ld[t] == t;
+    }
     const uint64_t stride = (uint64_t)gridDim.x * SEL_THREADS;
-    for (uint64_t base = (uint64_t)blockIdx.x * SEL_THREADS; base < n; base += 4 * stride) {
-        uint64_t k[4];
-        bool ok[4];
+    for (uint64_t base = (uint64_t)blockIdx.x * SEL_THREADS; base < n; base += SEL_UNROLL * stride) {
+        uint64_t k[SEL_UNROLL];
+        bool ok[SEL_UNROLL];
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
+        for (int u = 0; u < SEL_UNROLL; u++) {
             const uint64_t i = base + u * stride + threadIdx.x;
             ok[u] = i < n;
             k[u] = ok[u] ? key_of(keys[i]) : 0;
         }
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
+        for (int u = 0; u < SEL_UNROLL; u++) {
             if (!ok[u]) continue;
             const uint32_t hi = (uint32_t)(k[u] >> SEL_SH0), d = (uint32_t)(k[u] >> SEL_SH1) & (SEL_NB1 - 1);
 #pragma unroll
@@ -219,53 +215,52 @@ __global__ __launch_bounds__(SEL_THREADS) void k_sel_gather(const double *__rest
                                                             uint32_t *__restrict__ count)
 {
     __shared__ uint32_t pre[SEL_T];  // the 22 resolved bits
-    __shared__ uint64_t buf[4 * SEL_THREADS];
+    __shared__ uint64_t buf[SEL_GATHER_ROUND * SEL_THREADS];
     __shared__ uint32_t lcount, gbase;
     if (threadIdx.x == 0) lcount = 0;
-    if (threadIdx.x < 64) {
-        const int lane = (int)threadIdx.x;
-        uint64_t p1[SEL_T], r1[SEL_T], np[SEL_T], nr[SEL_T];
+    if (threadIdx.x < 64 * SEL_T) {  // a wave per target
+        const int lane = (int)threadIdx.x & 63, t = (int)threadIdx.x >> 6;
+        uint64_t p1[SEL_T];
         int ld[SEL_T];
 #pragma unroll
-        for (int t = 0; t < SEL_T; t++) { p1[t] = state1[2 * t]; r1[t] = state1[2 * t + 1]; }
+        for (int u = 0; u < SEL_T; u++) p1[u] = state1[2 * u];
         sel_leaders(p1, ld);
+        int mine = 0;
+        uint64_t pt = 0;
 #pragma unroll
-        for (int t = 0; t < SEL_T; t++) {
-            const uint32_t *hist = hist1 + ld[t] * SEL_NB1;
-            uint64_t lsum, inc, below;
-            uint32_t bin;
-            sel_scan<SEL_NB1>(lane, hist, lsum, inc);
-            sel_pick<SEL_NB1>(lane, hist, lsum, inc, r1[t], bin, below);
-            np[t] = p1[t] | ((uint64_t)bin << SEL_SH1);
-            nr[t] = r1[t] - below;
-        }
+        for (int u = 0; u < SEL_T; u++)
+            if (u == t) { mine = ld[u]; pt = p1[u]; }
+        const uint64_t r1 = state1[2 * t + 1];
+        const uint32_t *hist = hist1 + mine * SEL_NB1;
+        uint64_t lsum, inc, below;
+        uint32_t bin;
+        sel_scan<SEL_NB1>(lane, hist, lsum, inc);
+        sel_pick<SEL_NB1>(lane, hist, lsum, inc, r1, bin, below);
         if (lane == 0) {
-#pragma unroll
-            for (int t = 0; t < SEL_T; t++) {
-                pre[t] = (uint32_t)(np[t] >> SEL_SH1);
-                if (blockIdx.x == 0) { state2[2 * t] = np[t]; state2[2 * t + 1] = nr[t]; }
-            }
+            const uint64_t np = pt | ((uint64_t)bin << SEL_SH1);
+            pre[t] = (uint32_t)(np >> SEL_SH1);
+            if (blockIdx.x == 0) { state2[2 * t] = np; state2[2 * t + 1] = r1 - below; }
         }
     }
     __syncthreads();
     uint32_t lp[SEL_T];
 #pragma unroll
     for (int t = 0; t < SEL_T; t++) lp[t] = pre[t];
-    // matches of a round (4 keys per thread) go to LDS first, then to the list with ONE global atomic per workgroup:
+    // matches of a round (SEL_GATHER_ROUND keys per thread) go to LDS first, then to the list with ONE global atomic per workgroup:
     // returning atomics to one address run at ~14 ns each (one per matching wave took 140 us at 10^4 matches)
     const int lane = threadIdx.x & 63;
     const uint64_t stride = (uint64_t)gridDim.x * SEL_THREADS;
-    for (uint64_t base = (uint64_t)blockIdx.x * SEL_THREADS; base < n; base += 4 * stride) {
-        uint64_t k[4];
-        bool ok[4];
+    for (uint64_t base = (uint64_t)blockIdx.x * SEL_THREADS; base < n; base += SEL_GATHER_ROUND * stride) {
+        uint64_t k[SEL_GATHER_ROUND];
+        bool ok[SEL_GATHER_ROUND];
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
+        for (int u = 0; u < SEL_GATHER_ROUND; u++) {
             const uint64_t i = base + u * stride + threadIdx.x;
             ok[u] = i < n;
             k[u] = ok[u] ? key_of(keys[i]) : 0;
         }
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
+        for (int u = 0; u < SEL_GATHER_ROUND; u++) {
             const uint32_t hi = (uint32_t)(k[u] >> SEL_SH1);
             bool m = false;
 #pragma unroll
@@ -382,28 +377,22 @@ __global__ __launch_bounds__(SEL_THREADS) void k_sel_finish(sel_quart_t q, const
         }
         __syncthreads();
         if (threadIdx.x == 0 && !cached) n_cache = 0;
-        if (threadIdx.x < 64) {
-            const int lane = (int)threadIdx.x;
-            uint64_t np[SEL_T], nr[SEL_T];
-#pragma unroll
-            for (int t = 0; t < SEL_T; t++) {
-                const uint32_t *hist = &h[leader[t]][0];
-                const uint64_t r = st[2 * t + 1];
-                uint64_t lsum, inc, below;
-                uint32_t bin;
-                if (step == 0) {
-                    sel_scan<SEL_FIN_NB>(lane, hist, lsum, inc);
-                    sel_pick<SEL_FIN_NB>(lane, hist, lsum, inc, r, bin, below);
-                } else {
-                    sel_scan<256>(lane, hist, lsum, inc);
-                    sel_pick<256>(lane, hist, lsum, inc, r, bin, below);
-                }
-                np[t] = st[2 * t] | ((uint64_t)bin << shift);
-                nr[t] = r - below;
+        if (threadIdx.x < 64 * SEL_T) {  // a wave per target (it touches only its own two words of st)
+            const int lane = (int)threadIdx.x & 63, t = (int)threadIdx.x >> 6;
+            const uint32_t *hist = &h[leader[t]][0];
+            const uint64_t r = st[2 * t + 1];
+            uint64_t lsum, inc, below;
+            uint32_t bin;
+            if (step == 0) {
+                sel_scan<SEL_FIN_NB>(lane, hist, lsum, inc);
+                sel_pick<SEL_FIN_NB>(lane, hist, lsum, inc, r, bin, below);
+            } else {
+                sel_scan<256>(lane, hist, lsum, inc);
+                sel_pick<256>(lane, hist, lsum, inc, r, bin, below);
             }
             if (lane == 0) {
-#pragma unroll
-                for (int t = 0; t < SEL_T; t++) { st[2 * t] = np[t]; st[2 * t + 1] = nr[t]; }
+                st[2 * t] |= (uint64_t)bin << shift;
+                st[2 * t + 1] = r - below;
             }
         }
         __syncthreads();
@@ -516,7 +505,7 @@ cellector_status select_threshold(cellector_ctx *c, const double *keys, uint64_t
     uint32_t *hist0 = c->sel_hist, *hist1 = hist0 + SEL_NB0, *count = hist1 + SEL_T * SEL_NB1;
     uint64_t *state1 = c->sel_state, *state2 = c->sel_state + 2 * SEL_T;
     timer_begin(c, CELLECTOR_K_SELECT);
-    uint64_t g = (n + SEL_THREADS * 4 - 1) / (SEL_THREADS * 4);
+    uint64_t g = (n + SEL_THREADS * SEL_UNROLL - 1) / (SEL_THREADS * SEL_UNROLL);
     if (g > SEL_GRID) g = SEL_GRID;
     hipLaunchKernelGGL(k_sel_top, dim3((unsigned)g), dim3(SEL_THREADS), 0, c->stream, keys, n, hist0);
     hipLaunchKernelGGL(k_sel_mid, dim3((unsigned)g), dim3(SEL_THREADS), 0, c->stream, keys, n, r, hist0, state1, hist1);

@@ -934,7 +934,7 @@ __global__ __launch_bounds__(LR_THREADS) void k_minority_ranges(int locus_mode, 
                                                                const uint32_t *__restrict__ mroff,
                                                                const uint64_t *__restrict__ mbeg,
                                                                const uint32_t *__restrict__ c4r,
-                                                               uint32_t *__restrict__ hist_min /*[n_sub][L][16]*/)
+                                                               uint32_t *__restrict__ hist_min /*[n_sub][L][16] u16*/)
 {
     const uint32_t n_min = *n_min_p;
     if (!locus_by_minority(locus_mode, n_min, nloc, n_sub)) return;
@@ -1005,12 +1005,19 @@ __global__ __launch_bounds__(LR_THREADS) void k_minority_ranges(int locus_mode, 
 #undef LR_PREFETCH
 #undef LR_COUNT
     __syncthreads();
-    // this subset's plane of the range, as [locus][16] u32 (codes 14, 15: zero)
+    // this subset's plane of the range, as [locus][16] u16 like the counters (codes 14, 15: zero): 32 bytes per locus
+    // and plane for this kernel to write and k_locus_finalize to read
     const uint64_t nl = min((uint64_t)LR_LOCI, L - l0);
-    uint32_t *dst = hist_min + ((uint64_t)sub * L + l0) * 16;
-    for (uint32_t i = tid; i < nl * 16; i += LR_THREADS) {
-        const uint32_t code = i & 15u, idx = code * LR_ROW + (i >> 4);
-        dst[i] = code < (uint32_t)T_NCODE ? (s_hist[idx >> 1] >> ((idx & 1u) * 16u)) & 0xffffu : 0u;
+    uint32_t *dst = reinterpret_cast<uint32_t *>(reinterpret_cast<uint16_t *>(hist_min) + ((uint64_t)sub * L + l0) * 16);
+    for (uint32_t i = tid; i < nl * 8; i += LR_THREADS) {
+        const uint32_t lo = i >> 3, c0 = (i & 7u) * 2u;
+        uint32_t v = 0;
+#pragma unroll
+        for (uint32_t h = 0; h < 2; h++) {
+            const uint32_t code = c0 + h, idx = code * LR_ROW + lo;
+            if (code < (uint32_t)T_NCODE) v |= ((s_hist[idx >> 1] >> ((idx & 1u) * 16u)) & 0xffffu) << (16u * h);
+        }
+        dst[i] = v;
     }
 }
 
@@ -1037,7 +1044,8 @@ __global__ __launch_bounds__(256) void k_locus_finalize(uint64_t L, int locus_mo
                                                         const uint64_t *__restrict__ ovc_ent,
                                                         const double *__restrict__ ovf_lp, double *__restrict__ out)
 {
-    const int nplanes = locus_by_minority(locus_mode, *n_min_p, nloc, n_sub) ? (int)n_sub : 1;
+    // the minority-driven form left n_sub planes of u16 counts, the streamed form one plane of u32 counts
+    const bool by_min = locus_by_minority(locus_mode, *n_min_p, nloc, n_sub);
     const uint32_t j = threadIdx.x % LF_LANES;
     const uint64_t l_raw = ((uint64_t)blockIdx.x * 256 + threadIdx.x) / LF_LANES;
     const bool in = l_raw < L;
@@ -1050,7 +1058,12 @@ __global__ __launch_bounds__(256) void k_locus_finalize(uint64_t L, int locus_mo
     uint64_t amin = 0, rmin = 0;
     if (j < T_NCODE) {
         uint32_t cnt = 0;
-        for (int p = 0; p < nplanes; p++) cnt += hist_min[((uint64_t)p * L + l) * 16 + j];
+        if (by_min) {
+            const uint16_t *h16 = reinterpret_cast<const uint16_t *>(hist_min);
+            for (uint32_t p = 0; p < n_sub; p++) cnt += h16[((uint64_t)p * L + l) * 16 + j];
+        } else {
+            cnt = hist_min[l * 16 + j];
+        }
         const uint32_t h_all = hist_all[l * T_NCODE + j];
         // (element stride 2 when the table holds (log-pmf, expected) pairs)
         const double t_code = tab[(l / T_BLU) * TAB_ELEMS + (l % T_BLU) * T_LROW + j];
