@@ -30,8 +30,13 @@ void timer_begin(cellector_ctx *c, int which)
     if (!c->timing) return;
     // an event pair costs a few microseconds of idle queue: level 2 keeps only the pair the roofline figure needs
     if (c->timing == 2 && which != (c->engine == 2 ? CELLECTOR_K_TILE_LL : CELLECTOR_K_CELL_LL)) return;
-    hipEvent_t a, b;
-    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+    hipEvent_t a = nullptr, b = nullptr;
+    if (c->ev_pool.size() >= 2) {
+        a = c->ev_pool.back(); c->ev_pool.pop_back();
+        b = c->ev_pool.back(); c->ev_pool.pop_back();
+    } else if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) {
+        return;
+    }
     c->timers[which].start.push_back(a);
     c->timers[which].stop.push_back(b);
     (void)hipEventRecord(a, c->stream);
@@ -55,8 +60,8 @@ void timer_collect(cellector_ctx *c)
                 t.total_ms += ms;
                 t.launches++;
             }
-            (void)hipEventDestroy(t.start[i]);
-            (void)hipEventDestroy(t.stop[i]);
+            c->ev_pool.push_back(t.start[i]);
+            c->ev_pool.push_back(t.stop[i]);
         }
         t.start.clear();
         t.stop.clear();
@@ -225,6 +230,8 @@ void cellector_destroy(cellector_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->side) (void)hipStreamSynchronize(c->side);
     timer_collect(c);
+    for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
+    c->ev_pool.clear();
     free_matrix(c);
     dev_free(c->lf); dev_free(c->d_counters); dev_free(c->sel_hist); dev_free(c->sel_state); dev_free(c->sel_out);
     dev_free(c->sel_list);
@@ -251,7 +258,15 @@ cellector_status cellector_set_option(cellector_ctx *c, const char *key, int64_t
 {
     if (!c || !key) return CELLECTOR_EINVAL;
     if (!strcmp(key, "compute_expected")) c->compute_expected = v != 0;
-    else if (!strcmp(key, "timing")) c->timing = v < 0 ? 0 : (v > 2 ? 2 : (int)v);
+    else if (!strcmp(key, "timing")) {
+        c->timing = v < 0 ? 0 : (v > 2 ? 2 : (int)v);
+        if (c->timing && hipSetDevice(c->device) == hipSuccess)  // events ready before the timed loop starts
+            while (c->ev_pool.size() < 64) {
+                hipEvent_t e;
+                if (hipEventCreate(&e) != hipSuccess) break;
+                c->ev_pool.push_back(e);
+            }
+    }
     else if (!strcmp(key, "keep_coo")) c->keep_coo = v != 0;
     else if (!strcmp(key, "overlap")) {
         if (v < 0 || v > 2) return ctx_fail(c, CELLECTOR_EINVAL, "overlap must be 0, 1 or 2");
@@ -640,7 +655,9 @@ cellector_status cellector_em_finish(cellector_ctx *c, cellector_iter_summary *o
     c->iteration++;
     c->have_iter = true;
     c->em_phase = 0;
-    if (c->timing) timer_collect(c);
+    // (timers are read out when asked for — cellector_kernel_time — not here: waiting for the last event pair and destroying
+    //  the events is host time on the path to the next iteration's first launch; a long run is drained now and then)
+    if (c->timing && c->timers[CELLECTOR_K_TILE_LL].start.size() + c->timers[CELLECTOR_K_CELL_LL].start.size() > 512) timer_collect(c);
     if (out) {
         out->n_new_excluded = (uint64_t)cnt[LC_N_NEW];
         out->n_rescued = (uint64_t)cnt[LC_N_RESCUED];

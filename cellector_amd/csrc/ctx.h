@@ -161,6 +161,7 @@ struct cellector_ctx {
     bool have_iter = false;
 
     KernelTimer timers[CELLECTOR_K_COUNT];
+    std::vector<hipEvent_t> ev_pool;  // collected timer events, reused (creating a pair costs microseconds before a launch)
 };
 
 #define SEL_T 6
