@@ -92,6 +92,7 @@ def main():
         k, v = kv.split("=")
         g.set_option(k, int(v))
     g.set_shard(cb, ce)
+    g.set_option("norm_zero", 0)  # the NORM slices are all-gathered below, not summed: no need to clear the others' first
 
     def allreduce(t, op=None):
         if world > 1:

@@ -273,6 +273,11 @@ cellector_status cellector_set_option(cellector_ctx *c, const char *key, int64_t
         c->overlap = (int)v;
     }
     else if (!strcmp(key, "side_lds")) c->side_lds = (int)v;
+    else if (!strcmp(key, "norm_zero")) c->norm_zero = v != 0;
+    else if (!strcmp(key, "tile_groups")) {
+        if (v < 0 || v > 64 || v % 8) return ctx_fail(c, CELLECTOR_EINVAL, "tile_groups must be 0 (automatic) or a multiple of 8 up to 64");
+        c->tile_groups_opt = (int)v;
+    }
     else if (!strcmp(key, "locus_mode")) {
         if (v < 0 || v > 2) return ctx_fail(c, CELLECTOR_EINVAL, "locus_mode must be 0 (automatic), 1 (stream) or 2 (minority-driven)");
         c->locus_mode = (int)v;
@@ -577,7 +582,7 @@ cellector_status cellector_em_begin(cellector_ctx *c)
     // engine 2 forms alpha/beta inside its first kernel (k_build_tables); an empty shard has no cell pass at all
     if (c->engine != 2 || c->prebuilt_expected != c->compute_expected) c->tables_prebuilt = false;
     if (c->engine != 2 || c->nloc == 0) CHK(launch_alpha_beta(c));
-    if (c->nloc != c->total_cells)  // other shards' slices must be zero before the sum-exchange
+    if (c->nloc != c->total_cells && c->norm_zero)  // other shards' slices must be zero before a SUM exchange
         HIPCHK(c, hipMemsetAsync(c->x_norm, 0, c->total_cells * 8, c->stream));
     cellector_status st = c->engine == 2 ? tiled_cell_pass(c, c->ab, c->x_norm + c->cell_begin, true)
                                          : launch_cell_ll(c, c->ab, c->x_norm + c->cell_begin);

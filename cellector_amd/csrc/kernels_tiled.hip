@@ -1401,10 +1401,13 @@ cellector_status tiled_build(cellector_ctx *c)
         int ncu = 256;
         (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, c->device);
         const uint64_t cols = (c->t_nb + T_SB_MAX - 1) / T_SB_MAX;
-        // every workgroup of a group walks the group's chunks once per column it fetches: the kernel takes
-        // rounds(g) x chunks(g) chunk-steps with rounds = ceil(columns / workgroups per group).  Take the multiple of 8
-        // with the shortest makespan (e.g. 49 columns: 8 groups need 2 rounds of 66 chunk-steps, 24 groups 5 rounds of 22),
-        // charging 1 % per extra 8 groups for the additional partial sums.
+        // every workgroup of a group walks the group's chunks once per column it fetches: the kernel takes about
+        // rounds(g) x (chunks(g) + 3) chunk-steps with rounds = ceil(columns / workgroups per group) — a column costs its
+        // chunks plus a fixed part (accumulators cleared and written out as partial sums), put at three chunk-steps.
+        // Take the multiple of 8 with the shortest makespan, charging 3 % per extra 8 groups for the additional partial
+        // sums (16 bytes more per cell and pass written by the tile kernel and read by the finalize).  Few groups win on
+        // big matrices (measured: 8 groups 2.48 ms per iteration at 10^6 cells, 32 groups 2.59; 200k cells: 8 groups 0.435,
+        // 24 groups 0.447), more groups only where 8 leave CUs without a column (50k cells: 13 columns).
         uint64_t groups = T_GROUPS;
         double best = 1e300;
         for (uint64_t g = T_GROUPS; g <= T_GROUPS_MAX && g <= (uint64_t)c->t_nj; g += T_GROUPS) {
@@ -1412,9 +1415,10 @@ cellector_status tiled_build(cellector_ctx *c)
             if (per < 1) per = 1;
             if (per > cols) per = cols;
             const uint64_t rounds = (cols + per - 1) / per, chunks = ((uint64_t)c->t_nj + g - 1) / g;
-            const double cost = (double)(rounds * chunks) * (1.0 + 0.01 * (double)(g / T_GROUPS - 1));
+            const double cost = (double)(rounds * (chunks + 3)) * (1.0 + 0.03 * (double)(g / T_GROUPS - 1));
             if (cost < best) { best = cost; groups = g; }
         }
+        if (c->tile_groups_opt > 0) groups = (uint64_t)c->tile_groups_opt;  // (A/B runs)
         if (groups > c->t_nj) groups = c->t_nj;
         c->t_groups = (uint32_t)groups;
     }

@@ -63,7 +63,11 @@ cellector_status cellector_set_stream(cellector_ctx *ctx, void *hip_stream);
  * "overlap" (engine 2, default 1: the kernels of the few entries with alt+ref = 0 or > 4 run on a side
  * stream beside the table-lookup kernel; 2 = their locus-side part only after that kernel; 0 = everything
  * in one stream; same results to the bit),
- * "side_lds" (engine 2, default -1: automatic residency throttle of the side-stream kernels). */
+ * "side_lds" (engine 2, default -1: automatic residency throttle of the side-stream kernels),
+ * "tile_groups" (engine 2, default 0: the number of locus-chunk groups of the tile kernel is chosen per matrix;
+ * a multiple of 8 up to 64 forces it — set before ingest; results may differ in the last bit),
+ * "norm_zero" (default 1: a shard clears the other shards' slices of CELLECTOR_XCHG_NORM before it writes
+ * its own, so that a SUM all-reduce completes the array; 0 when the caller all-gathers the slices). */
 cellector_status cellector_set_option(cellector_ctx *ctx, const char *key, int64_t value);
 
 /* ---- sharding (before ingest) --------------------------------------------------------------- */

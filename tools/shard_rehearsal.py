@@ -15,6 +15,7 @@ def main():
     ap.add_argument("--ranks", default="1,2,4,8")
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--opt", action="append", default=[], help="key=value context option (repeatable)")
     args = ap.parse_args()
     import torch
     from bench import WORKLOADS
@@ -26,6 +27,9 @@ def main():
         per = (N + R - 1) // R
         g = Cellector(0, stream=torch.cuda.current_stream().cuda_stream)
         g.set_option("keep_coo", 0)
+        for kv in args.opt:
+            k, v = kv.split("=")
+            g.set_option(k, int(v))
         g.set_shard(0, per)
         x_pass1 = torch.zeros(5 * L_total, dtype=torch.float64, device=dev)
         g.bind_exchange_buffer(ffi.XCHG_PASS1, x_pass1.data_ptr(), x_pass1.numel())
