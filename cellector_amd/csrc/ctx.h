@@ -107,7 +107,7 @@ struct cellector_ctx {
     uint64_t *ovf_ptr = nullptr, *ovf_ent = nullptr;    // overflow CSR (alt+ref == 0 or > 4), packed like csr_ent
     uint64_t ovf_n = 0;
     double *ovf_tab = nullptr;       // [L][128] per-locus cumulative-log / expected tables for overflow entries
-    double *ovf_etab = nullptr;      // [L][4] E(n), n = 5..8: compact copy for the cell side
+    double *ovf_etab = nullptr;      // [L][8] alpha, beta, E(n) for n = 5..8, pad: the cell side's 64-byte record per locus
     int side_lds = -1;               // option "side_lds": dynamic LDS bytes requested by the cell-side overflow kernel (residency
                                      // throttle; -1 = automatic)
     bool ovf_locus_pending = false;  // the side stream still owes this iteration's ovf_lp (event ev_join2)

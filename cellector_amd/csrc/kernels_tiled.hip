@@ -405,6 +405,7 @@ __device__ __forceinline__ double ov_expected_rec(double alpha, double beta, uin
 // k_ovf_tables_e = one thread per (locus, n) for the totals n that occur among the locus' overflow entries (nmask: static).
 #define OV_ROW 128
 #define OV_EOFF 64
+#define OV_REC 8  // the cell side's per-locus record: alpha, beta, E(5..8), pad = ONE 64-byte sector per overflow entry
 __global__ __launch_bounds__(256) void k_ovf_tables(uint64_t L, const double2 *__restrict__ ab, double *__restrict__ otab)
 {
     const uint64_t idx = (uint64_t)blockIdx.x * 256 + threadIdx.x;
@@ -428,18 +429,22 @@ __global__ __launch_bounds__(256) void k_ovf_tables(uint64_t L, const double2 *_
 }
 __global__ __launch_bounds__(256) void k_ovf_tables_e(uint64_t L, const double2 *__restrict__ ab,
                                                       const uint32_t *__restrict__ nmask, double *__restrict__ otab,
-                                                      double *__restrict__ etab /*[L][4]: E(5..8), the cell side's compact copy*/)
+                                                      double *__restrict__ etab /*[L][OV_REC]: the cell side's record*/)
 {
     const uint64_t idx = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    const uint64_t l = idx >> 4;  // 16 slots per locus, 14 used
+    const uint64_t l = idx >> 4;  // 16 slots per locus: 14 totals, the last one copies alpha / beta
     if (l >= L) return;
     const uint32_t i = (uint32_t)(idx & 15u);
+    if (i == 15u) {  // (a masked locus carries its negative alpha along: the cell side tests that)
+        *reinterpret_cast<double2 *>(etab + l * OV_REC) = ab[l];
+        return;
+    }
     if (i > (uint32_t)OV_NE - 4u || !((nmask[l] >> i) & 1u)) return;
     const double2 p = ab[l];
     if (!(p.x >= 0.0)) return;
     const double e = ov_expected_rec(p.x, p.y, 4u + i);
     otab[l * OV_ROW + OV_EOFF + i] = e;
-    if (i >= 1 && i <= 4) etab[l * 4 + (i - 1)] = e;
+    if (i >= 1 && i <= 4) etab[l * OV_REC + 2 + (i - 1)] = e;
 }
 
 // one thread per overflow entry, by-locus order: neighbouring threads share a locus, so the three table words an entry
@@ -509,12 +514,17 @@ __global__ __launch_bounds__(256) void k_ovf_nmask(uint64_t L, const uint64_t *_
 // all-ones to the group's longest row): a wave's loads are coalesced and every line is used once.  Reading the CSR row by
 // row, a lane per row, re-fetched each row's 128-byte line for every one of its entries (measured 2.1 GB for 0.13 GB).
 #define OVF_PAD (~0ull)
-template <bool EXPECTED>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(48))) void k_ovf_cell_direct(
+// PACKED (a big shard's EM pass): alpha, beta and the expected terms out of ONE 64-byte record per locus (k_ovf_tables_e).
+// Gathered from two tables an entry fetches two sectors — 2.0 GB per pass at cfg4 on the fabric the tile kernel streams
+// through, 1.0 GB this way.  The variant needs 64 VGPRs, i.e. one wave per SIMD beside the tile kernel: all a big shard's
+// launch asks for (residency throttle, launch_overflow_cell); a small shard wants two and keeps the 48-VGPR form.
+template <bool EXPECTED, bool PACKED>
+__global__ __launch_bounds__(256) void k_ovf_cell_direct(
     uint64_t n_rows, const uint64_t *__restrict__ ell_ptr, const uint64_t *__restrict__ ell,
     const double2 *__restrict__ ab, const double *__restrict__ lf, const double *__restrict__ etab,
     const double *__restrict__ otab, double *__restrict__ o_ll, double *__restrict__ o_ell)
 {
+    static_assert(EXPECTED || !PACKED, "the record is built for the EM pass");
     const uint64_t row = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (row >= n_rows) return;  // (rows beyond the end have no lane; their slots are padding)
     double s = 0.0, e = 0.0;
@@ -524,7 +534,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(48))) void k_ov
         const uint64_t en = ell[i];
         if (en == OVF_PAD) continue;
         const uint32_t l = ENT_IDX(en), a = ENT_ALT(en), r = ENT_REF(en), n = a + r;
-        const double2 p = ab[l];
+        const double *rec = etab + (uint64_t)l * OV_REC;
+        const double2 p = PACKED ? *reinterpret_cast<const double2 *>(rec) : ab[l];
+        double ev = 0.0;  // (an overflow entry has a total of 0 or above T_K: the record covers T_K + 1 .. OV_FAST_N)
+        if (PACKED) ev = n > (uint32_t)T_K && n <= (uint32_t)OV_FAST_N ? rec[n - 3] : 0.0;
         // masked locus: no PMFData (main.rs:556); 0/0 entry: exactly zero (Q14); a total above OV_FAST_N: k_ovf_cell_listed
         if (!(p.x >= 0.0) || n == 0 || n > (uint32_t)OV_FAST_N) continue;
         // = dm_log_bb_pmf for these totals: ln C out of the factorial table, one log of a ratio of products of <= 8 factors
@@ -535,7 +548,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(48))) void k_ov
             den *= abs_ + (double)k;
         }
         s += (lf[n] - lf[a] - lf[r]) + log(num / den);
-        if (EXPECTED) e += n >= 5 ? etab[(uint64_t)l * 4 + (n - 5)] : otab[(uint64_t)l * OV_ROW + OV_EOFF + (n - 4)];
+        if (EXPECTED) {
+            if (PACKED) e += ev;
+            else e += n >= 5 ? rec[2 + (n - 5)] : otab[(uint64_t)l * OV_ROW + OV_EOFF + (n - 4)];
+        }
     }
     o_ll[row] = s;
     if (EXPECTED) o_ell[row] = e;
@@ -1502,7 +1518,7 @@ cellector_status tiled_build(cellector_ctx *c)
     CHK(dev_alloc(c, &c->ovf_sum, 3 * 2 * nloc));
     CHK(dev_alloc(c, &c->ovf_lp, c->ovf_n));
     CHK(dev_alloc(c, &c->ovf_tab, L * OV_ROW));
-    CHK(dev_alloc(c, &c->ovf_etab, L * 4));
+    CHK(dev_alloc(c, &c->ovf_etab, L * OV_REC));
     CHK(dev_alloc(c, &c->ovf_nmask, L));
     CHK(dev_alloc(c, &c->ovc_locus, c->ovf_n));
     {
@@ -1604,8 +1620,12 @@ static void launch_overflow_cell(cellector_ctx *c, hipStream_t st, const double2
         // a tile workgroup (one wave per SIMD instead of two).  On a big shard the kernel still ends well inside the tile
         // kernel and disturbs it less (cfg4: 2.83 -> 2.78 ms per iteration); a small shard's tile kernel is too short for that.
         const size_t lds_req = c->side_lds >= 0 ? (size_t)c->side_lds : (st == c->side && c->nloc >= (1ull << 19) ? 5000 : 0);
-        hipLaunchKernelGGL(k_ovf_cell_direct<true>, dim3(g), dim3(256), lds_req, st, c->nloc, c->ovf_ell_ptr, c->ovf_ell, ab, c->lf,
-                           c->ovf_etab, c->ovf_tab, o_ll, o_ell);
+        if (lds_req)  // one block per CU: the 64-VGPR form with the packed per-locus record
+            hipLaunchKernelGGL((k_ovf_cell_direct<true, true>), dim3(g), dim3(256), lds_req, st, c->nloc, c->ovf_ell_ptr, c->ovf_ell,
+                               ab, c->lf, c->ovf_etab, c->ovf_tab, o_ll, o_ell);
+        else
+            hipLaunchKernelGGL((k_ovf_cell_direct<true, false>), dim3(g), dim3(256), 0, st, c->nloc, c->ovf_ell_ptr, c->ovf_ell, ab,
+                               c->lf, c->ovf_etab, c->ovf_tab, o_ll, o_ell);
         if (c->ovf_n_tier[0])
             hipLaunchKernelGGL((k_ovf_cell_listed<true, false>), dim3(gcap(c->ovf_n_tier[0], 256, 0x7fffffffu)), dim3(256), 0, st,
                                c->ovf_n_tier[0], c->ovf_tier_row[0], c->ovf_tier_ent[0], ab, c->lf, c->ovf_tab, o_ll, o_ell);
@@ -1613,7 +1633,7 @@ static void launch_overflow_cell(cellector_ctx *c, hipStream_t st, const double2
             hipLaunchKernelGGL((k_ovf_cell_listed<true, true>), dim3(gcap(c->ovf_n_tier[1], 256, 0x7fffffffu)), dim3(256), 0, st,
                                c->ovf_n_tier[1], c->ovf_tier_row[1], c->ovf_tier_ent[1], ab, c->lf, c->ovf_tab, o_ll, o_ell);
     } else {
-        hipLaunchKernelGGL(k_ovf_cell_direct<false>, dim3(g), dim3(256), 0, st, c->nloc, c->ovf_ell_ptr, c->ovf_ell, ab, c->lf,
+        hipLaunchKernelGGL((k_ovf_cell_direct<false, false>), dim3(g), dim3(256), 0, st, c->nloc, c->ovf_ell_ptr, c->ovf_ell, ab, c->lf,
                            c->ovf_etab, c->ovf_tab, o_ll, o_ell);
         if (c->ovf_n_tier[0])
             hipLaunchKernelGGL((k_ovf_cell_listed<false, false>), dim3(gcap(c->ovf_n_tier[0], 256, 0x7fffffffu)), dim3(256), 0, st,

@@ -193,9 +193,12 @@ def test_overflow_side_stream_equals_in_stream(mods):
     al = np.where(big, al * rng.integers(1, 12, len(al)), al).astype(np.uint32)
     re = np.where(big, re * rng.integers(1, 12, len(re)), re).astype(np.uint32)
     outs = []
-    for ov in (1, 0, 2):  # beside the lookup kernel (default) / in one stream / locus-side values after the lookup kernel
+    # beside the lookup kernel (default) / in one stream / locus-side values after the lookup kernel / the side kernels under
+    # the residency throttle a big shard gets (which also selects the packed-record form of the cell-side kernel)
+    for ov, lds in ((1, -1), (0, -1), (2, -1), (1, 5000)):
         g = mods["Cellector"](0)
         g.set_option("overlap", ov)
+        g.set_option("side_lds", lds)
         g.load_coo(L, N, lo, ce, al, re)
         o = mods["ob"].Oracle.from_coo(L, N, lo, ce, al, re)
         run = []
