@@ -138,7 +138,7 @@ struct cellector_ctx {
     uint64_t *mbeg = nullptr;        // [mroff_cap] start of the excluded cells' rows in csr_ent
     uint64_t mroff_cap = 0;
     uint32_t lr_sub = 1;             // subsets of the exclusion set = partial planes of hist_min
-    uint32_t *c4r = nullptr;         // [nnz] compact by-cell entries locus | code << 28 (code 15: overflow entry)
+    uint16_t *c4r = nullptr;         // [nnz] compact by-cell entries: locus inside its 4096-locus range | code << 12 (code 15: overflow entry)
     uint32_t *roff = nullptr;        // [nloc][R+1] offsets of the locus ranges inside each by-cell CSR row
     int locus_mode = 0;              // option "locus_mode": 0 = chosen on the device per iteration, 1 = stream the compact CSC,
                                      // 2 = minority-driven tally over the by-cell CSR

@@ -876,12 +876,13 @@ __global__ __launch_bounds__(LS_THREADS) void k_locus_stats2(uint64_t L, uint32_
 
 // compact by-cell entries for k_minority_ranges: locus | code << 28 (code 15: an overflow entry, not counted there) —
 // half the bytes of the packed CSR entry, and that kernel runs at the memory rate
-__global__ __launch_bounds__(256) void k_cell_compact(uint64_t nnz, const uint64_t *__restrict__ csr_ent, uint32_t *__restrict__ c4r)
+__global__ __launch_bounds__(256) void k_cell_compact(uint64_t nnz, const uint64_t *__restrict__ csr_ent, uint16_t *__restrict__ c4r)
 {
+    static_assert(LR_LOCI == 4096, "12 bits of locus inside its range + 4 bits of code");
     const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= nnz) return;
     const uint64_t e = csr_ent[i];
-    c4r[i] = ENT_IDX(e) | ((ent_regular(e) ? ent_code(e) : 15u) << 28);
+    c4r[i] = (uint16_t)((ENT_IDX(e) % LR_LOCI) | ((ent_regular(e) ? ent_code(e) : 15u) << 12));
 }
 
 // roff[cell][r] = number of the row's entries with locus < r * LR_LOCI, r = 0..R (row sorted by locus).  Wave per row.
@@ -949,7 +950,7 @@ __global__ __launch_bounds__(LR_THREADS) void k_minority_ranges(int locus_mode, 
                                                                const uint32_t *__restrict__ n_min_p,
                                                                const uint32_t *__restrict__ mroff,
                                                                const uint64_t *__restrict__ mbeg,
-                                                               const uint32_t *__restrict__ c4r,
+                                                               const uint16_t *__restrict__ c4r,
                                                                uint32_t *__restrict__ hist_min /*[n_sub][L][16] u16*/)
 {
     const uint32_t n_min = *n_min_p;
@@ -968,8 +969,8 @@ __global__ __launch_bounds__(LR_THREADS) void k_minority_ranges(int locus_mode, 
     const uint32_t grp = lane / LR_GROUP, gl = lane % LR_GROUP;
 #define LR_COUNT(E)                                                                                              \
     do {                                                                                                         \
-        if (((E) >> 28) < (uint32_t)T_NCODE) {                                                                   \
-            const uint32_t idx__ = ((E) >> 28) * LR_ROW + (((E) & 0x0fffffffu) - l0);                            \
+        if (((E) >> 12) < (uint32_t)T_NCODE) {                                                                   \
+            const uint32_t idx__ = ((E) >> 12) * LR_ROW + ((E) & 0x0fffu);                                       \
             atomicAdd(&s_hist[idx__ >> 1], 1u << ((idx__ & 1u) * 16u));                                          \
         }                                                                                                        \
     } while (0)
@@ -1002,7 +1003,7 @@ __global__ __launch_bounds__(LR_THREADS) void k_minority_ranges(int locus_mode, 
 #pragma unroll
             for (int u = 0; u < NQ; u++) {
                 const uint32_t seg = wv * 64 + (q0 + u) * SPW + grp;
-                e[u] = gl < s_len[seg] ? c4r[s_beg[seg] + gl] : ~0u;  // all ones: code 15, not counted
+                e[u] = gl < s_len[seg] ? (uint32_t)c4r[s_beg[seg] + gl] : 0xffffu;  // all ones: code 15, not counted
             }
 #pragma unroll
             for (int u = 0; u < NQ; u++) LR_COUNT(e[u]);
@@ -1011,7 +1012,7 @@ __global__ __launch_bounds__(LR_THREADS) void k_minority_ranges(int locus_mode, 
                 const uint32_t sn = s_len[seg];
                 const uint64_t sb = s_beg[seg];
                 for (uint32_t j = gl + LR_GROUP; j < sn; j += LR_GROUP) {
-                    const uint32_t x = c4r[sb + j];
+                    const uint32_t x = (uint32_t)c4r[sb + j];
                     LR_COUNT(x);
                 }
             }
