@@ -131,7 +131,7 @@ __global__ __launch_bounds__(64 * TB_PARTS) void k_build_tables(uint64_t L, uint
 // cell pass over the tiles
 // ---------------------------------------------------------------------------------------------------------
 #ifndef TILE_ABL
-#define TILE_ABL 0  // ablation builds of the tile kernel (tools/gpu_ab.sh): 1 no lookups, 2 no entry loads, 3 no table re-staging
+#define TILE_ABL 0  // ablation builds of the tile kernel (tools/gpu_ab.sh): 1 no lookups, 2 no entry loads, 3 no table re-staging, 4 conflict-free lookups
 #endif
 // Workgroup barrier that waits for this wave's LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it would wait
 // for the prefetch loads in flight and make them synchronous.
@@ -240,6 +240,13 @@ __global__ __launch_bounds__(T_THREADS, 4) void k_tile_ll(uint32_t nb, uint32_t 
     // and wave-uniform, so the lookups come in pairs behind one scalar branch.
 #if TILE_ABL == 1  /* ablation: no table lookups */
 #define TILE_LOOKUP(V, E16) do { if constexpr (EXPECTED) V = make_double2((double)(E16), 1.0); else V = (double)(E16); } while (0)
+#elif TILE_ABL == 4  /* ablation: lookups free of bank conflicts (a lane keeps to its own bank pair; wrong values) */
+#define TILE_LOOKUP(V, E16)                                                                                      \
+    do {                                                                                                         \
+        const uint32_t b__ = (((E16) >> 4) & 127u) * 32u + (lane & 31u), c__ = (((E16) >> 5) & 127u) * 32u + (lane & 31u); \
+        if constexpr (EXPECTED) V = make_double2(s_tab[b__], s_tab[c__ + 4096u]);                                \
+        else V = s_tab[b__];                                                                                     \
+    } while (0)
 #else
 #define TILE_LOOKUP(V, E16)                                                                                      \
     do {                                                                                                         \
