@@ -1,3 +1,7 @@
+#!/bin/bash
+# usage (on the GPU box, through gpurun): bash tools/gpu_timeline.sh <tag>
+# GPU test-suite, then kernel timelines (tools/timeline.py) of the last EM iterations of rank 0's shard at 1 and 8 ranks
+# (tools/shard_rehearsal.py under rocprofv3 --kernel-trace), the default bench line and the shard rehearsal.
 export TMPDIR=/tmp
 out=gpurun_out/$1; mkdir -p $out
 timeout -k 10 900 python -m pytest tests -m gpu -x -q > $out/pytest_gpu.log 2>&1; rc=$?
