@@ -37,7 +37,7 @@ def parse():
     ap.add_argument("--workload", default=os.environ.get("CELLECTOR_BENCH_WORKLOAD", "cfg4"), choices=list(WORKLOADS))
     ap.add_argument("--seed", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-entries", type=float, default=1.5e7,
+    ap.add_argument("--cpu-sample-entries", type=float, default=4e7,
                     help="size of the CPU-baseline sample in matrix entries (~1 us/entry/pass on one core)")
     ap.add_argument("--engine", type=int, default=2, choices=[1, 2],
                     help="2 = table-driven tiled passes (default), 1 = CSR/CSC kernels evaluating every entry")
