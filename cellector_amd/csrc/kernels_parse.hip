@@ -16,6 +16,8 @@
 #include <zlib.h>
 
 #include <chrono>
+#include <condition_variable>
+#include <mutex>
 #include <thread>
 
 #include "ctx.h"
@@ -95,8 +97,12 @@ __device__ bool token_u32(const uint8_t *__restrict__ p, const uint8_t *__restri
 // NL_SEG bytes (line 0 at byte 0, line k after the k-th newline; off[t] = newlines before the segment, from the scan of
 // k_nl_count) — no array of line starts is ever materialised (at 2e9 lines per file that array was 16 GB of VRAM each).
 #define PARSE_TAIL 64  // bytes staged beyond the block's segments: a line that starts near the end finishes in there
+// Windowed use (big files, parse_windowed below): `text` is one window of the data section plus look-ahead bytes, n_count
+// the bytes whose newlines belong to this window, line_base the number of newlines before the window, first = the window
+// starts at the first data byte (line 0 has no newline before it), more = the file goes on beyond the n bytes given.
 template <bool ALT>
-__global__ __launch_bounds__(PB) void k_parse_lines(const uint8_t *__restrict__ text, uint64_t n, uint64_t n_lines,
+__global__ __launch_bounds__(PB) void k_parse_lines(const uint8_t *__restrict__ text, uint64_t n, uint64_t n_count, uint64_t n_lines,
+                                                    uint64_t line_base, bool first, bool more,
                                                     const uint64_t *__restrict__ off, uint32_t *__restrict__ o0,
                                                     uint32_t *__restrict__ o1, uint32_t *__restrict__ o2,
                                                     unsigned long long *__restrict__ first_bad)
@@ -110,19 +116,27 @@ __global__ __launch_bounds__(PB) void k_parse_lines(const uint8_t *__restrict__ 
     __syncthreads();
     const uint64_t t = (uint64_t)blockIdx.x * PB + threadIdx.x;
     const uint64_t base = t * NL_SEG;
-    if (base >= n) return;
+    if (base >= n_count) return;
     auto line = [&](uint64_t i, uint64_t start) {
         if (i >= n_lines || start >= n) return;
         uint32_t v[3] = {0, 0, 0};
         // inside the staged window (a line is far shorter than the tail) parse from LDS, else from the text itself
         const uint64_t rel = start - blk;
         const uint8_t *p = text + start, *e = text + n;
+        bool closed = false;
         if (rel + PARSE_TAIL <= avail) {
             const uint8_t *q = s_text + rel, *qe = q + PARSE_TAIL;
-            bool closed = false;
             for (const uint8_t *z = q; z < qe; z++)
                 if (*z == '\n') { closed = true; break; }
             if (closed) { p = q; e = qe; }
+        }
+        if (!closed && more) {  // a line that runs out of the window's look-ahead: not supported (PW_LOOK bytes)
+            for (const uint8_t *z = p; z < e; z++)
+                if (*z == '\n') { closed = true; break; }
+            if (!closed) {
+                atomicMin(first_bad, (unsigned long long)i);
+                return;
+            }
         }
         const bool ok = ALT ? token_u32(p, e, 0, 3, v) : token_u32(p, e, 2, 1, v);
         if (!ok) {
@@ -131,12 +145,12 @@ __global__ __launch_bounds__(PB) void k_parse_lines(const uint8_t *__restrict__ 
         }
         if (ALT) { o0[i] = v[0]; o1[i] = v[1]; o2[i] = v[2]; } else o2[i] = v[0];
     };
-    if (t == 0) line(0, 0);
-    uint64_t k = off[t];
+    if (t == 0 && first) line(line_base, 0);
+    uint64_t k = line_base + off[t];
     for (int u = 0; u < NL_SEG / 16; u++) {
         const uint64_t ub = base + 16 * u;
-        if (ub >= n) break;
-        uint32_t m = newline_mask16(text, n, ub);
+        if (ub >= n_count) break;
+        uint32_t m = newline_mask16(text, n_count, ub);
         while (m) {
             const int b = __ffs((int)m) - 1;
             m &= m - 1;
@@ -156,7 +170,7 @@ __global__ __launch_bounds__(PB) void k_pair_check(uint64_t n, const uint32_t *_
 {
     const uint64_t i = (uint64_t)blockIdx.x * PB + threadIdx.x;
     if (i > n) return;
-    if (i == n) { keep[i] = 0; return; }
+    if (i == n) { if (keep) keep[i] = 0; return; }
     uint32_t kind = PE_NONE;
     if (l1[i] == 0 || c1[i] == 0) kind = PE_INDEX0;          // `tok - 1` underflows in the reference
     else if (l1[i] > total_loci) kind = PE_LOCUS;
@@ -164,12 +178,12 @@ __global__ __launch_bounds__(PB) void k_pair_check(uint64_t n, const uint32_t *_
     else if (a[i] > CELLECTOR_MAX_COUNT || r[i] > CELLECTOR_MAX_COUNT) kind = PE_COUNT;
     if (kind != PE_NONE) {
         if (atomicMin(first_bad, (unsigned long long)i) > i) *bad_kind = kind;  // best effort: kind of the smallest seen
-        keep[i] = 0;
+        if (keep) keep[i] = 0;
         return;
     }
     const uint64_t c0 = c1[i] - 1;
     const bool mine = c0 >= cb && c0 < ce;
-    keep[i] = mine ? 1 : 0;
+    if (keep) keep[i] = mine ? 1 : 0;  // (null: the shard holds every cell, every valid entry stays where it is)
     if (i + 1 < n && l1[i + 1] < l1[i]) *unsorted = 1;  // file order not locus-major (all entries, a superset check)
 }
 
@@ -190,22 +204,58 @@ __global__ __launch_bounds__(PB) void k_pair_fill(uint64_t n, const uint32_t *__
     o_ref[p] = (uint16_t)r[i];
 }
 
+// a shard that holds every cell: the token arrays BECOME the staged COO (indices made 0-based in place, counts narrowed
+// into two new u16 arrays) — no keep flags, no scan, no second copy of the indices: 32 GB less fresh VRAM at 2e9 entries
+__global__ __launch_bounds__(PB) void k_pair_take(uint64_t n, uint32_t *__restrict__ l1, uint32_t *__restrict__ c1,
+                                                  const uint32_t *__restrict__ a, const uint32_t *__restrict__ r,
+                                                  uint16_t *__restrict__ o_alt, uint16_t *__restrict__ o_ref)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * PB + threadIdx.x;
+    if (i >= n) return;
+    l1[i] -= 1;
+    c1[i] -= 1;
+    o_alt[i] = (uint16_t)a[i];
+    o_ref[i] = (uint16_t)r[i];
+}
+
 // ===============================================================================================================
 namespace {
 
+// the bytes of one input file: inflated into `owned` (.gz), mapped (plain, below FB_UNMAPPED), or — a multi-GB plain
+// file — not mapped at all: its windows are pread() straight into the pinned upload buffers.  (Mapping 2 x 31 GB meant
+// 15 M page-table entries to fault in and to tear down again: the munmap alone took 0.7 s, during which the runtime's
+// own allocations queue for the address-space lock.)
+#define FB_UNMAPPED (4ull << 30)
 struct FileBytes {
-    const uint8_t *data = nullptr;
+    const uint8_t *data = nullptr;  // null: unmapped, use read()
     size_t size = 0;
     void *map = nullptr;
     size_t map_len = 0;
     int fd = -1;
-    std::vector<uint8_t> owned;
+    std::vector<uint8_t> owned;  // .gz: the inflated file; unmapped: its first FB_HEAD bytes (the header lines)
+    size_t head_len = 0;
     ~FileBytes()
     {
         if (map) munmap(map, map_len);
         if (fd >= 0) close(fd);
     }
+    const uint8_t *head() const { return data ? data : owned.data(); }
+    size_t head_size() const { return data ? size : head_len; }
+    bool read(size_t off, size_t len, uint8_t *dst) const
+    {
+        if (data) {
+            memcpy(dst, data + off, len);
+            return true;
+        }
+        while (len) {
+            const ssize_t got = pread(fd, dst, len, (off_t)off);
+            if (got <= 0) return false;
+            dst += got; off += (size_t)got; len -= (size_t)got;
+        }
+        return true;
+    }
 };
+#define FB_HEAD (1u << 20)
 
 // reader (load_data.rs:240-251): ".gz" by extension (multi-member), plain otherwise
 bool load_bytes(const char *path, FileBytes *fb)
@@ -233,6 +283,12 @@ bool load_bytes(const char *path, FileBytes *fb)
     struct stat st;
     if (fstat(fb->fd, &st) != 0) return false;
     fb->size = (size_t)st.st_size;
+    const char *um = getenv("CELLECTOR_UNMAPPED_MIN");  // (tests: the unmapped path on small files)
+    if (fb->size >= (um ? (size_t)strtoull(um, nullptr, 10) : (size_t)FB_UNMAPPED) && fb->size > 0) {
+        fb->head_len = std::min<size_t>(fb->size, FB_HEAD);
+        fb->owned.resize(fb->head_len);
+        return fb->read(0, fb->head_len, fb->owned.data());
+    }
     if (fb->size) {
         fb->map = mmap(nullptr, fb->size, PROT_READ, MAP_PRIVATE, fb->fd, 0);
         if (fb->map == MAP_FAILED) { fb->map = nullptr; return false; }
@@ -248,10 +304,13 @@ size_t skip_header(const FileBytes &fb, std::string *third)
 {
     size_t pos = 0;
     for (int x = 0; x < 3; x++) {
-        const void *nl = pos < fb.size ? memchr(fb.data + pos, '\n', fb.size - pos) : nullptr;
-        const size_t end = nl ? (size_t)((const uint8_t *)nl - fb.data) : fb.size;
-        if (x == 2 && third) third->assign((const char *)fb.data + pos, end - pos);
-        pos = nl ? end + 1 : fb.size;
+        // (an unmapped file: the three lines are looked for in its first FB_HEAD bytes)
+        const uint8_t *hd = fb.head();
+        const size_t hn = fb.head_size();
+        const void *nl = pos < hn ? memchr(hd + pos, '\n', hn - pos) : nullptr;
+        const size_t end = nl ? (size_t)((const uint8_t *)nl - hd) : hn;
+        if (x == 2 && third) third->assign((const char *)hd + pos, end - pos);
+        pos = nl ? end + 1 : hn;
     }
     return pos;
 }
@@ -359,12 +418,188 @@ cellector_status split_lines(cellector_ctx *c, const FileBytes &fb, DevText *dt)
     return CELLECTOR_OK;
 }
 
+// ---- windowed parse of one file -------------------------------------------------------------------------------
+// A multi-GB data section never resides on the device as a whole: a producer thread copies windows of it (plus PW_LOOK
+// bytes of look-ahead: a line that starts in a window may end behind it) through pinned buffers into one of PW_NB device
+// buffers, the caller's thread counts the window's newlines, scans them and tokenises the lines that start there straight
+// into the token arrays, at the running line count.  The text of BASELINE configs[4] is 2 x 31 GB: as one allocation per
+// file it cost 65 GB of fresh VRAM (30-50 ms per GB to map) before the first line was parsed.
+#define PW_LOOK (1ull << 20)  // the longest line a windowed file may hold
+#define PW_NB 3
+#define PW_WINDOW (256ull << 20)
+#define PW_THREADS 8  // host threads filling a pinned buffer (pread out of the page cache; 16 threads measured no faster)
+
+template <typename T>
+cellector_status grow_tokens(cellector_ctx *c, T **arr, uint64_t used, uint64_t new_cap)
+{
+    T *bigger = nullptr;
+    CHK(dev_alloc(c, &bigger, new_cap));
+    hipError_t e = hipSuccess;
+    if (used) e = hipMemcpyAsync(bigger, *arr, used * sizeof(T), hipMemcpyDeviceToDevice, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) {
+        dev_free(bigger);
+        return ctx_fail(c, CELLECTOR_EDEVICE, "parse: %s", hipGetErrorString(e));
+    }
+    dev_free(*arr);
+    *arr = bigger;
+    return CELLECTOR_OK;
+}
+
+// tokens of every line of the data section: ALT -> o0, o1, o2 (locus, cell, count), else o2 only (count); arrays are
+// allocated here (capacity from the header's entry count, grown if the file holds more lines)
+template <bool ALT>
+cellector_status parse_windowed(cellector_ctx *c, const FileBytes &fb, size_t data_off, uint64_t window, uint64_t cap_hint,
+                                uint32_t **o0, uint32_t **o1, uint32_t **o2, uint64_t *n_lines, unsigned long long *bad)
+{
+    const uint64_t nb = fb.size - data_off;
+    *n_lines = 0;
+    uint64_t cap = (cap_hint ? cap_hint : nb / 12) + 16;
+    if (ALT) { CHK(dev_alloc(c, o0, cap)); CHK(dev_alloc(c, o1, cap)); }
+    CHK(dev_alloc(c, o2, cap));
+    if (nb == 0) return CELLECTOR_OK;
+    if (window < 4 * NL_SEG) window = 4 * NL_SEG;
+    window &= ~(uint64_t)(NL_SEG - 1);
+    uint8_t last_byte = '\n';
+    if (!fb.read(data_off + nb - 1, 1, &last_byte)) return ctx_fail(c, CELLECTOR_EIO, "cannot read the input file");
+    const bool unterminated = last_byte != '\n';
+    const uint64_t n_win = (nb + window - 1) / window;
+    const size_t buf_bytes = window + PW_LOOK + 64;
+    uint8_t *pin[PW_NB] = {}, *dev[PW_NB] = {};
+    hipEvent_t ev_up[PW_NB] = {}, ev_free[PW_NB] = {};
+    hipStream_t up = nullptr;
+    uint64_t *seg = nullptr;
+    const uint64_t seg_cap = window / NL_SEG + 2;
+    hipError_t e = hipStreamCreateWithFlags(&up, hipStreamNonBlocking);
+    const int nbuf = (int)std::min<uint64_t>(PW_NB, n_win);
+    for (int b = 0; b < nbuf && e == hipSuccess; b++) {
+        e = hipHostMalloc((void **)&pin[b], buf_bytes);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&ev_up[b], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&ev_free[b], hipEventDisableTiming);
+        if (e == hipSuccess && dev_alloc(c, &dev[b], buf_bytes) != CELLECTOR_OK) e = hipErrorOutOfMemory;
+    }
+    if (e == hipSuccess && dev_alloc(c, &seg, seg_cap) != CELLECTOR_OK) e = hipErrorOutOfMemory;
+    std::mutex mu;
+    std::condition_variable cv;
+    uint64_t produced = 0, consumed = 0;
+    bool stop = false;
+    hipError_t perr = hipSuccess;
+    cellector_status st = e == hipSuccess ? CELLECTOR_OK : ctx_fail(c, CELLECTOR_EDEVICE, "parse buffers: %s", hipGetErrorString(e));
+    if (st == CELLECTOR_OK) {
+        std::thread producer([&] {
+            hipError_t pe = hipSetDevice(c->device);
+            for (uint64_t w = 0; w < n_win && pe == hipSuccess; w++) {
+                const int b = (int)(w % PW_NB);
+                if (w >= PW_NB) {  // the buffer's previous window has been tokenised
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv.wait(lk, [&] { return consumed + PW_NB > w || stop; });
+                    if (stop) return;
+                    lk.unlock();
+                    pe = hipEventSynchronize(ev_free[b]);
+                    if (pe != hipSuccess) break;
+                }
+                const uint64_t o = w * window;
+                const size_t len = (size_t)std::min<uint64_t>(window + PW_LOOK, nb - o);
+                std::thread th[PW_THREADS];
+                bool got[PW_THREADS];
+                const size_t slice = (len + PW_THREADS - 1) / PW_THREADS;
+                for (int t = 0; t < PW_THREADS; t++)
+                    th[t] = std::thread([&, t] {
+                        const size_t b0 = std::min(len, (size_t)t * slice), b1 = std::min(len, b0 + slice);
+                        got[t] = b1 <= b0 || fb.read(data_off + o + b0, b1 - b0, pin[b] + b0);
+                    });
+                for (int t = 0; t < PW_THREADS; t++) th[t].join();
+                for (int t = 0; t < PW_THREADS; t++)
+                    if (!got[t]) pe = hipErrorFileNotFound;  // (reported as the upload's failure)
+                if (pe != hipSuccess) break;
+                memset(pin[b] + len, '\n', 32);  // the end of the data terminates a last line without '\n' (BufRead::lines)
+                pe = hipMemcpyAsync(dev[b], pin[b], len + 32, hipMemcpyHostToDevice, up);
+                if (pe == hipSuccess) pe = hipEventRecord(ev_up[b], up);
+                if (pe != hipSuccess) break;
+                {
+                    std::lock_guard<std::mutex> lk(mu);
+                    produced = w + 1;
+                }
+                cv.notify_all();
+            }
+            if (pe != hipSuccess) {
+                std::lock_guard<std::mutex> lk(mu);
+                perr = pe;
+                stop = true;
+            }
+            cv.notify_all();
+        });
+        uint64_t line_base = 0;
+        for (uint64_t w = 0; w < n_win && st == CELLECTOR_OK; w++) {
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return produced > w || stop; });
+                if (produced <= w) {
+                    st = ctx_fail(c, CELLECTOR_EDEVICE, "text upload: %s", hipGetErrorString(perr));
+                    break;
+                }
+            }
+            const int b = (int)(w % PW_NB);
+            const uint64_t o = w * window, in_win = std::min<uint64_t>(window, nb - o);
+            const uint64_t len = std::min<uint64_t>(window + PW_LOOK, nb - o);
+            const bool last = w + 1 == n_win, more = o + len < nb;
+            const uint64_t n_count = in_win + (last && unterminated ? 1 : 0);  // (the padding newline closes the last line)
+            const uint64_t n_buf = len + (last && unterminated ? 1 : 0);
+            const uint64_t nseg = (n_count + NL_SEG - 1) / NL_SEG;
+            e = hipStreamWaitEvent(c->stream, ev_up[b], 0);
+            if (e == hipSuccess) e = hipMemsetAsync(seg, 0, (nseg + 1) * 8, c->stream);
+            if (e != hipSuccess) { st = ctx_fail(c, CELLECTOR_EDEVICE, "parse: %s", hipGetErrorString(e)); break; }
+            hipLaunchKernelGGL(k_nl_count, dim3(pgrid(nseg)), dim3(PB), 0, c->stream, dev[b], n_count, seg);
+            uint64_t n_nl = 0;
+            st = dev_exclusive_scan_u64(c, seg, nseg + 1, &n_nl);
+            if (st != CELLECTOR_OK) break;
+            if (line_base + n_nl + 1 > cap) {
+                const uint64_t want = std::max(line_base + n_nl + 16, cap + cap / 2);
+                if (ALT) { st = grow_tokens(c, o0, line_base + 1, want); if (st == CELLECTOR_OK) st = grow_tokens(c, o1, line_base + 1, want); }
+                if (st == CELLECTOR_OK) st = grow_tokens(c, o2, line_base + 1, want);
+                if (st != CELLECTOR_OK) break;
+                cap = want;
+            }
+            hipLaunchKernelGGL(k_parse_lines<ALT>, dim3(pgrid(nseg)), dim3(PB), 0, c->stream, dev[b], n_buf, n_count, cap, line_base,
+                               w == 0, more, seg, ALT ? *o0 : (uint32_t *)nullptr, ALT ? *o1 : (uint32_t *)nullptr, *o2, bad);
+            e = hipEventRecord(ev_free[b], c->stream);
+            if (e != hipSuccess) { st = ctx_fail(c, CELLECTOR_EDEVICE, "parse: %s", hipGetErrorString(e)); break; }
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                consumed = w + 1;
+            }
+            cv.notify_all();
+            line_base += n_nl;
+        }
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            if (st != CELLECTOR_OK) stop = true;
+        }
+        cv.notify_all();
+        producer.join();
+        e = hipStreamSynchronize(c->stream);
+        if (st == CELLECTOR_OK && e != hipSuccess) st = ctx_fail(c, CELLECTOR_EDEVICE, "parse: %s", hipGetErrorString(e));
+        if (st == CELLECTOR_OK) *n_lines = line_base;
+    }
+    if (up) (void)hipStreamSynchronize(up);
+    for (int b = 0; b < PW_NB; b++) {
+        if (ev_up[b]) (void)hipEventDestroy(ev_up[b]);
+        if (ev_free[b]) (void)hipEventDestroy(ev_free[b]);
+        if (pin[b]) (void)hipHostFree(pin[b]);
+        dev_free(dev[b]);
+    }
+    dev_free(seg);
+    if (up) (void)hipStreamDestroy(up);
+    return st;
+}
+
 }  // namespace
 
 struct MtxInput {
     FileBytes fa, fr;
     size_t off_a = 0, off_r = 0;
     uint64_t total_loci = 0, total_cells = 0;
+    uint64_t nnz_hint = 0;  // third number of the size line (0: absent); a capacity hint, never trusted
 };
 
 // open both files (bytes only) and read the dims from the REF file's third header line (load_data.rs:216-220)
@@ -388,6 +623,8 @@ cellector_status mtx_input_open(const cellector_ctx *c, const char *alt_path, co
         in->off_r = skip_header(in->fr, &third);
         if (!host_tok_u64(third, 0, &in->total_loci) || !host_tok_u64(third, 1, &in->total_cells))
             st = ctx_fail(c, CELLECTOR_EPARSE, "cannot parse the matrix market size line of %s", ref_path);
+        else if (!host_tok_u64(third, 2, &in->nnz_hint) || in->nnz_hint > (in->fr.size - in->off_r) / 4)
+            in->nnz_hint = 0;  // (a line holds at least "1 1 1": a hint beyond the bytes there are is nonsense)
     }
     if (st != CELLECTOR_OK) {
         delete in;
@@ -401,12 +638,33 @@ cellector_status mtx_input_open(const cellector_ctx *c, const char *alt_path, co
 
 void mtx_input_close(MtxInput *in) { delete in; }
 
+// a file small enough to sit on the device whole: one upload, one scan of its newlines, one tokeniser launch
+template <bool ALT>
+static cellector_status parse_whole(cellector_ctx *c, const FileBytes &fb, size_t data_off, uint32_t **o0, uint32_t **o1,
+                                    uint32_t **o2, uint64_t *n_lines, unsigned long long *bad)
+{
+    DevText t;
+    cellector_status st = upload_text(c, fb, data_off, &t);
+    if (st == CELLECTOR_OK) st = split_lines(c, fb, &t);
+    const uint64_t n = t.n_lines;
+    if (st == CELLECTOR_OK && ALT) { st = dev_alloc(c, o0, n); if (st == CELLECTOR_OK) st = dev_alloc(c, o1, n); }
+    if (st == CELLECTOR_OK) st = dev_alloc(c, o2, n);
+    if (st == CELLECTOR_OK && n) {
+        hipLaunchKernelGGL(k_parse_lines<ALT>, dim3(pgrid(t.n_seg)), dim3(PB), 0, c->stream, t.text, t.n, t.n, n, 0ull, true, false,
+                           t.seg_off, ALT ? *o0 : (uint32_t *)nullptr, ALT ? *o1 : (uint32_t *)nullptr, *o2, bad);
+        const hipError_t e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) st = ctx_fail(c, CELLECTOR_EDEVICE, "parse: %s", hipGetErrorString(e));
+    }
+    dev_free(t.text); dev_free(t.seg_off);
+    *n_lines = n;
+    return st;
+}
+
 // Stage this shard's entries of the alt/ref pair on the device; dims / shard range must already be set on the ctx.
 cellector_status ingest_stage_mtx_device(cellector_ctx *c, MtxInput *in)
 {
     FileBytes &fa = in->fa, &fr = in->fr;
     const size_t off_a = in->off_a, off_r = in->off_r;
-    DevText ta, tr;
     const bool timing = getenv("CELLECTOR_TIMING") != nullptr;  // phase wall times on stderr
     auto t_prev = std::chrono::steady_clock::now();
     auto lap = [&](const char *what) {
@@ -416,20 +674,10 @@ cellector_status ingest_stage_mtx_device(cellector_ctx *c, MtxInput *in)
         fprintf(stderr, "[timing]     %-22s %8.3f s\n", what, std::chrono::duration<double>(now - t_prev).count());
         t_prev = now;
     };
-    cellector_status st = CELLECTOR_OK, st_r = CELLECTOR_OK;
-    // (one after the other: two host threads copying side by side measured three times slower)
-    st = upload_text(c, fa, off_a, &ta);
-    if (st == CELLECTOR_OK) st_r = upload_text(c, fr, off_r, &tr);
-    if (st == CELLECTOR_OK) st = st_r;
-    lap("text upload");
-    if (st == CELLECTOR_OK) st = split_lines(c, fa, &ta);
-    if (st == CELLECTOR_OK) st = split_lines(c, fr, &tr);
-    lap("line starts");
     uint32_t *l1 = nullptr, *c1 = nullptr, *a = nullptr, *r = nullptr, *flags = nullptr;
-    unsigned long long *bad = nullptr;
+    unsigned long long *bad = nullptr;  // [0] alt file, [1] ref file: smallest line that does not parse; [2] zip stage
     uint64_t *keep = nullptr;
     auto cleanup = [&]() {
-        dev_free(ta.text); dev_free(ta.seg_off); dev_free(tr.text); dev_free(tr.seg_off);
         dev_free(l1); dev_free(c1); dev_free(a); dev_free(r); dev_free(flags); dev_free(bad); dev_free(keep);
     };
 #define PCHK(expr)                     \
@@ -440,52 +688,68 @@ cellector_status ingest_stage_mtx_device(cellector_ctx *c, MtxInput *in)
             return s__;                \
         }                              \
     } while (0)
-    PCHK(st);
-    const uint64_t n = std::min(ta.n_lines, tr.n_lines);  // izip!: stops at the shorter file
-    PCHK(dev_alloc(c, &l1, n)); PCHK(dev_alloc(c, &c1, n)); PCHK(dev_alloc(c, &a, n)); PCHK(dev_alloc(c, &r, n));
-    PCHK(dev_alloc(c, &bad, 2)); PCHK(dev_alloc(c, &flags, 4));
-    lap("token arrays (alloc)");
-    unsigned long long h_bad[2] = {~0ull, ~0ull};
+    HIPCHK(c, hipSetDevice(c->device));
+    PCHK(dev_alloc(c, &bad, 3)); PCHK(dev_alloc(c, &flags, 4));
+    unsigned long long h_bad[3] = {~0ull, ~0ull, ~0ull};
     uint32_t h_flags[4] = {0, 0, 0, 0};
     hipError_t e = hipMemcpy(bad, h_bad, sizeof h_bad, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(flags, h_flags, sizeof h_flags, hipMemcpyHostToDevice);
     if (e != hipSuccess) { cleanup(); return ctx_fail(c, CELLECTOR_EDEVICE, "parse: %s", hipGetErrorString(e)); }
-    if (n) {
-        hipLaunchKernelGGL(k_parse_lines<true>, dim3(pgrid(ta.n_seg)), dim3(PB), 0, c->stream, ta.text, ta.n, n, ta.seg_off, l1, c1,
-                           a, bad);
-        hipLaunchKernelGGL(k_parse_lines<false>, dim3(pgrid(tr.n_seg)), dim3(PB), 0, c->stream, tr.text, tr.n, n, tr.seg_off,
-                           (uint32_t *)nullptr, (uint32_t *)nullptr, r, bad);
-    }
+    // a multi-GB file goes through the device in windows (option parse_window forces a window size: tests); the token
+    // arrays' capacity comes from the size line's entry count (a hint only: the reference never reads it)
+    uint64_t n_a = 0, n_r = 0;
+    const uint64_t win = c->parse_window_opt > 0 ? (uint64_t)c->parse_window_opt : PW_WINDOW;
+    if (c->parse_window_opt > 0 || !fa.data || fa.size - off_a >= UP_MIN)
+        PCHK((parse_windowed<true>(c, fa, off_a, win, in->nnz_hint, &l1, &c1, &a, &n_a, bad)));
+    else
+        PCHK((parse_whole<true>(c, fa, off_a, &l1, &c1, &a, &n_a, bad)));
+    lap("alt file (upload + tokens)");
+    if (c->parse_window_opt > 0 || !fr.data || fr.size - off_r >= UP_MIN)
+        PCHK((parse_windowed<false>(c, fr, off_r, win, in->nnz_hint, (uint32_t **)nullptr, (uint32_t **)nullptr, &r, &n_r, bad + 1)));
+    else
+        PCHK((parse_whole<false>(c, fr, off_r, (uint32_t **)nullptr, (uint32_t **)nullptr, &r, &n_r, bad + 1)));
+    lap("ref file (upload + tokens)");
+    const uint64_t n = std::min(n_a, n_r);  // izip!: stops at the shorter file
     e = hipMemcpy(h_bad, bad, sizeof h_bad, hipMemcpyDeviceToHost);
     if (e != hipSuccess) { cleanup(); return ctx_fail(c, CELLECTOR_EDEVICE, "parse: %s", hipGetErrorString(e)); }
-    if (h_bad[0] != ~0ull) {
-        cleanup();
-        return ctx_fail(c, CELLECTOR_EPARSE, "cannot parse mtx entry %llu (line %llu of the data section)", h_bad[0], h_bad[0] + 1);
+    {   // (a line beyond the shorter file is never read by the reference: only failures among the first n count)
+        const unsigned long long first = std::min(h_bad[0], h_bad[1]);
+        if (first < n) {
+            cleanup();
+            return ctx_fail(c, CELLECTOR_EPARSE, "cannot parse mtx entry %llu (line %llu of the data section)", first, first + 1);
+        }
     }
-    // the text and the line starts are done with: hand their blocks back before the next arrays are allocated, so that the
-    // allocation cache can reuse them (every GB of fresh VRAM costs 30-50 ms)
-    dev_free(ta.text); dev_free(ta.seg_off); dev_free(tr.text); dev_free(tr.seg_off);
-    PCHK(dev_alloc(c, &keep, n + 1));
+    const bool all_cells = c->cell_begin == 0 && c->cell_end >= c->total_cells;
+    if (!all_cells) PCHK(dev_alloc(c, &keep, n + 1));
     hipLaunchKernelGGL(k_pair_check, dim3(pgrid(n + 1)), dim3(PB), 0, c->stream, n, l1, c1, a, r, c->total_loci, c->total_cells,
-                       c->cell_begin, c->cell_end, keep, bad + 1, flags, flags + 1);
+                       c->cell_begin, c->cell_end, keep, bad + 2, flags, flags + 1);
     e = hipMemcpy(h_bad, bad, sizeof h_bad, hipMemcpyDeviceToHost);
     if (e == hipSuccess) e = hipMemcpy(h_flags, flags, sizeof h_flags, hipMemcpyDeviceToHost);
     if (e != hipSuccess) { cleanup(); return ctx_fail(c, CELLECTOR_EDEVICE, "parse: %s", hipGetErrorString(e)); }
-    if (h_bad[1] != ~0ull) {
+    if (h_bad[2] != ~0ull) {
         cleanup();
         static const char *what[] = {"", "index 0 (indices are 1-based)", "locus index out of range", "cell index out of range",
                                      "count above 65535 not supported"};
-        return ctx_fail(c, CELLECTOR_EINVAL, "mtx entry %llu: %s", h_bad[1], what[h_flags[0] <= 4 ? h_flags[0] : 0]);
+        return ctx_fail(c, CELLECTOR_EINVAL, "mtx entry %llu: %s", h_bad[2], what[h_flags[0] <= 4 ? h_flags[0] : 0]);
     }
-    uint64_t kept = 0;
-    PCHK(dev_exclusive_scan_u64(c, keep, n + 1, &kept));
-    c->coo_n = kept;
     c->coo_sorted = h_flags[1] == 0;
-    PCHK(dev_alloc(c, &c->coo_locus, kept)); PCHK(dev_alloc(c, &c->coo_cell, kept));
-    PCHK(dev_alloc(c, &c->coo_alt, kept)); PCHK(dev_alloc(c, &c->coo_ref, kept));
-    if (n)
-        hipLaunchKernelGGL(k_pair_fill, dim3(pgrid(n)), dim3(PB), 0, c->stream, n, l1, c1, a, r, c->cell_begin, c->cell_end, keep,
-                           c->coo_locus, c->coo_cell, c->coo_alt, c->coo_ref);
+    if (all_cells) {
+        c->coo_n = n;
+        PCHK(dev_alloc(c, &c->coo_alt, n)); PCHK(dev_alloc(c, &c->coo_ref, n));
+        if (n) hipLaunchKernelGGL(k_pair_take, dim3(pgrid(n)), dim3(PB), 0, c->stream, n, l1, c1, a, r, c->coo_alt, c->coo_ref);
+        c->coo_locus = l1;
+        c->coo_cell = c1;
+        l1 = c1 = nullptr;  // (owned by the ctx now)
+    } else {
+        uint64_t kept = 0;
+        PCHK(dev_exclusive_scan_u64(c, keep, n + 1, &kept));
+        c->coo_n = kept;
+        PCHK(dev_alloc(c, &c->coo_locus, kept)); PCHK(dev_alloc(c, &c->coo_cell, kept));
+        PCHK(dev_alloc(c, &c->coo_alt, kept)); PCHK(dev_alloc(c, &c->coo_ref, kept));
+        if (n)
+            hipLaunchKernelGGL(k_pair_fill, dim3(pgrid(n)), dim3(PB), 0, c->stream, n, l1, c1, a, r, c->cell_begin, c->cell_end,
+                               keep, c->coo_locus, c->coo_cell, c->coo_alt, c->coo_ref);
+    }
     e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     lap("tokenise + zip + filter");

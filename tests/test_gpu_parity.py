@@ -534,6 +534,65 @@ def test_mtx_text_contract_on_device(mods, tmp_path):
     g.close()
 
 
+def test_windowed_text_parse_equals_whole_file_parse(mods, tmp_path):
+    """Files of 4 GB and more are uploaded and tokenised in windows (csrc/kernels_parse.hip, parse_windowed); option
+    parse_window forces that path with tiny windows here, so that lines straddle window ends everywhere: the staged matrix,
+    the error reporting and the text contract must be those of the whole-file path."""
+    if mods["engine"] != 2:
+        pytest.skip("ingest path: one engine is enough")
+    L, N = 700, 900
+    lo, ce, al, re = mods["synth"].generate_coo(L, N, 0.05, seed=21)
+    a_path, r_path = mods["synth"].write_mtx_pair(str(tmp_path), L, N, lo, ce, al, re)
+    # an unterminated last line and a ref file with a header of another length: the two files' windows never line up
+    with open(a_path, "rb") as f:
+        body = f.read()
+    with open(a_path, "wb") as f:
+        f.write(body.rstrip(b"\n"))
+    ref_lines = open(r_path).read().split("\n", 3)
+    open(r_path, "w").write(ref_lines[0] + "\n% a longer comment line than the alt file has, to shift every window\n" + ref_lines[2] + "\n" + ref_lines[3])
+    whole = mods["Cellector"](0)
+    whole.load_mtx(a_path, r_path, 2, 2)
+    for window in (512, 640, 4096, 1 << 16, -512):
+        g = mods["Cellector"](0)
+        g.set_option("parse_window", abs(window))
+        if window < 0:  # ... and the way files of 4 GB and more are read: never mapped, pread() into the upload buffers
+            os.environ["CELLECTOR_UNMAPPED_MIN"] = "1"
+        try:
+            g.load_mtx(a_path, r_path, 2, 2)
+        finally:
+            os.environ.pop("CELLECTOR_UNMAPPED_MIN", None)
+        dg, dw = g.dims(), whole.dims()
+        assert (dg.total_loci, dg.total_cells, dg.loci_used, dg.nnz_used) == (dw.total_loci, dw.total_cells, dw.loci_used, dw.nnz_used)
+        assert np.array_equal(g.locus_ids(), whole.locus_ids())
+        assert np.array_equal(g.locus_counts(), whole.locus_counts())
+        ra, ea = g.csr_rows(0, N)
+        rb, eb = whole.csr_rows(0, N)
+        assert np.array_equal(ra, rb) and np.array_equal(ea, eb), window
+        g.close()
+    whole.close()
+    # the text contract's corner cases through the windowed path (the size line promises fewer entries than there are:
+    # the token arrays grow)
+    alt, ref = tmp_path / "alt2.mtx", tmp_path / "ref2.mtx"
+    alt.write_text("%%MatrixMarket\n%\n99 99 1\n1 1 2\r\n1 2 +1\n2 1 0\n  2   2 3  \n2\t3\t1\n2 3 7")
+    ref.write_text("%%MatrixMarket\n%\n2 3 0\nx y 1\n8 8 0\n9 9 4\n1 1 1\n7 7 2\n")
+    g = mods["Cellector"](0)
+    g.set_option("parse_window", 512)
+    g.load_mtx(str(alt), str(ref), 1, 1)
+    d = g.dims()
+    assert (d.total_loci, d.total_cells, d.loci_used, d.nnz_used) == (2, 3, 2, 5)
+    g.close()
+    many = "".join(f"1 {1 + i % 3} 1\n" for i in range(400))  # several windows of 512 bytes
+    for name, body, where in (("float", many + "1 1 1.0\n" + many, 400), ("two_tokens", many + many + "1 1\n", 800)):
+        bad = tmp_path / f"w_{name}.mtx"
+        bad.write_text("%%MatrixMarket\n%\n2 3 0\n" + body)
+        g = mods["Cellector"](0)
+        g.set_option("parse_window", 512)
+        with pytest.raises(mods["ffi"].CellectorError) as ei:
+            g.load_mtx(str(bad), str(bad), 1, 1)
+        assert ei.value.status == 3 and f"entry {where} " in str(ei.value), (name, str(ei.value))
+        g.close()
+
+
 def test_sharded_mtx_ingest_equals_coo_ingest(mods, tmp_path):
     L, N = 400, 300
     lo, ce, al, re = mods["synth"].generate_coo(L, N, 0.2, seed=12)
