@@ -50,7 +50,7 @@ struct cellector_ctx {
 
     // options
     bool compute_expected = true;
-    int64_t parse_window_opt = 0;  // option parse_window: 0 = whole file below 4 GB, 256 MB windows above; else the window in bytes
+    int64_t parse_window_opt = 0;  // option parse_window: 0 = whole file below 1 GB, 256 MB windows above; else the window in bytes
     int tile_groups_opt = 0;  // option tile_groups: 0 = chosen per matrix (tiled_setup), else forced (multiple of 8)
     bool norm_zero = true;  // option: clear the other shards' slices of NORM before the cell pass (needed by a sum exchange)
     int timing = 0;  // 0 off, 1 every timed region, 2 only the dominant kernel of the engine

@@ -221,11 +221,11 @@ __global__ __launch_bounds__(PB) void k_pair_take(uint64_t n, uint32_t *__restri
 // ===============================================================================================================
 namespace {
 
-// the bytes of one input file: inflated into `owned` (.gz), mapped (plain, below FB_UNMAPPED), or — a multi-GB plain
-// file — not mapped at all: its windows are pread() straight into the pinned upload buffers.  (Mapping 2 x 31 GB meant
+// the bytes of one input file: inflated into `owned` (.gz), mapped (plain, below FB_UNMAPPED), or — a plain file of
+// FB_UNMAPPED bytes and more — not mapped at all: its windows are pread() straight into the pinned upload buffers.  (Mapping 2 x 31 GB meant
 // 15 M page-table entries to fault in and to tear down again: the munmap alone took 0.7 s, during which the runtime's
 // own allocations queue for the address-space lock.)
-#define FB_UNMAPPED (4ull << 30)
+#define FB_UNMAPPED (1ull << 30)
 struct FileBytes {
     const uint8_t *data = nullptr;  // null: unmapped, use read()
     size_t size = 0;
@@ -427,7 +427,45 @@ cellector_status split_lines(cellector_ctx *c, const FileBytes &fb, DevText *dt)
 #define PW_LOOK (1ull << 20)  // the longest line a windowed file may hold
 #define PW_NB 3
 #define PW_WINDOW (256ull << 20)
+#define PW_MIN (1ull << 30)  // data sections from this size on go through the windows
 #define PW_THREADS 8  // host threads filling a pinned buffer (pread out of the page cache; 16 threads measured no faster)
+
+// the windows' buffers, shared by the two files of a pair (pinning 3 x 257 MB takes ~0.05 s)
+struct PwBuffers {
+    uint8_t *pin[PW_NB] = {}, *dev[PW_NB] = {};
+    hipEvent_t ev_up[PW_NB] = {}, ev_free[PW_NB] = {};
+    hipStream_t up = nullptr;
+    uint64_t *seg = nullptr;
+    uint64_t window = 0;
+    int n = 0;
+    cellector_status make(cellector_ctx *c, uint64_t win, int count)
+    {
+        window = win;
+        const size_t buf_bytes = window + PW_LOOK + 64;
+        hipError_t e = hipStreamCreateWithFlags(&up, hipStreamNonBlocking);
+        for (int b = 0; b < count && e == hipSuccess; b++) {
+            e = hipHostMalloc((void **)&pin[b], buf_bytes);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&ev_up[b], hipEventDisableTiming);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&ev_free[b], hipEventDisableTiming);
+            if (e == hipSuccess && dev_alloc(c, &dev[b], buf_bytes) != CELLECTOR_OK) e = hipErrorOutOfMemory;
+            if (e == hipSuccess) n = b + 1;
+        }
+        if (e == hipSuccess && dev_alloc(c, &seg, window / NL_SEG + 2) != CELLECTOR_OK) e = hipErrorOutOfMemory;
+        return e == hipSuccess ? CELLECTOR_OK : ctx_fail(c, CELLECTOR_EDEVICE, "parse buffers: %s", hipGetErrorString(e));
+    }
+    ~PwBuffers()
+    {
+        if (up) (void)hipStreamSynchronize(up);
+        for (int b = 0; b < PW_NB; b++) {
+            if (ev_up[b]) (void)hipEventDestroy(ev_up[b]);
+            if (ev_free[b]) (void)hipEventDestroy(ev_free[b]);
+            if (pin[b]) (void)hipHostFree(pin[b]);
+            dev_free(dev[b]);
+        }
+        dev_free(seg);
+        if (up) (void)hipStreamDestroy(up);
+    }
+};
 
 template <typename T>
 cellector_status grow_tokens(cellector_ctx *c, T **arr, uint64_t used, uint64_t new_cap)
@@ -449,50 +487,40 @@ cellector_status grow_tokens(cellector_ctx *c, T **arr, uint64_t used, uint64_t 
 // tokens of every line of the data section: ALT -> o0, o1, o2 (locus, cell, count), else o2 only (count); arrays are
 // allocated here (capacity from the header's entry count, grown if the file holds more lines)
 template <bool ALT>
-cellector_status parse_windowed(cellector_ctx *c, const FileBytes &fb, size_t data_off, uint64_t window, uint64_t cap_hint,
+cellector_status parse_windowed(cellector_ctx *c, const FileBytes &fb, size_t data_off, PwBuffers &B, uint64_t cap_hint,
                                 uint32_t **o0, uint32_t **o1, uint32_t **o2, uint64_t *n_lines, unsigned long long *bad)
 {
+    const uint64_t window = B.window;
+    uint8_t *const *pin = B.pin, *const *dev = B.dev;
+    hipEvent_t *ev_up = B.ev_up, *ev_free = B.ev_free;
+    hipStream_t up = B.up;
+    uint64_t *seg = B.seg;
+    const uint64_t n_ring = (uint64_t)B.n;  // buffers in the ring
     const uint64_t nb = fb.size - data_off;
     *n_lines = 0;
     uint64_t cap = (cap_hint ? cap_hint : nb / 12) + 16;
     if (ALT) { CHK(dev_alloc(c, o0, cap)); CHK(dev_alloc(c, o1, cap)); }
     CHK(dev_alloc(c, o2, cap));
     if (nb == 0) return CELLECTOR_OK;
-    if (window < 4 * NL_SEG) window = 4 * NL_SEG;
-    window &= ~(uint64_t)(NL_SEG - 1);
     uint8_t last_byte = '\n';
     if (!fb.read(data_off + nb - 1, 1, &last_byte)) return ctx_fail(c, CELLECTOR_EIO, "cannot read the input file");
     const bool unterminated = last_byte != '\n';
     const uint64_t n_win = (nb + window - 1) / window;
-    const size_t buf_bytes = window + PW_LOOK + 64;
-    uint8_t *pin[PW_NB] = {}, *dev[PW_NB] = {};
-    hipEvent_t ev_up[PW_NB] = {}, ev_free[PW_NB] = {};
-    hipStream_t up = nullptr;
-    uint64_t *seg = nullptr;
-    const uint64_t seg_cap = window / NL_SEG + 2;
-    hipError_t e = hipStreamCreateWithFlags(&up, hipStreamNonBlocking);
-    const int nbuf = (int)std::min<uint64_t>(PW_NB, n_win);
-    for (int b = 0; b < nbuf && e == hipSuccess; b++) {
-        e = hipHostMalloc((void **)&pin[b], buf_bytes);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&ev_up[b], hipEventDisableTiming);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&ev_free[b], hipEventDisableTiming);
-        if (e == hipSuccess && dev_alloc(c, &dev[b], buf_bytes) != CELLECTOR_OK) e = hipErrorOutOfMemory;
-    }
-    if (e == hipSuccess && dev_alloc(c, &seg, seg_cap) != CELLECTOR_OK) e = hipErrorOutOfMemory;
+    hipError_t e = hipSuccess;
     std::mutex mu;
     std::condition_variable cv;
     uint64_t produced = 0, consumed = 0;
     bool stop = false;
     hipError_t perr = hipSuccess;
-    cellector_status st = e == hipSuccess ? CELLECTOR_OK : ctx_fail(c, CELLECTOR_EDEVICE, "parse buffers: %s", hipGetErrorString(e));
-    if (st == CELLECTOR_OK) {
+    cellector_status st = CELLECTOR_OK;
+    {
         std::thread producer([&] {
             hipError_t pe = hipSetDevice(c->device);
             for (uint64_t w = 0; w < n_win && pe == hipSuccess; w++) {
-                const int b = (int)(w % PW_NB);
-                if (w >= PW_NB) {  // the buffer's previous window has been tokenised
+                const int b = (int)(w % n_ring);
+                if (w >= n_ring) {  // the buffer's previous window has been tokenised
                     std::unique_lock<std::mutex> lk(mu);
-                    cv.wait(lk, [&] { return consumed + PW_NB > w || stop; });
+                    cv.wait(lk, [&] { return consumed + n_ring > w || stop; });
                     if (stop) return;
                     lk.unlock();
                     pe = hipEventSynchronize(ev_free[b]);
@@ -539,7 +567,7 @@ cellector_status parse_windowed(cellector_ctx *c, const FileBytes &fb, size_t da
                     break;
                 }
             }
-            const int b = (int)(w % PW_NB);
+            const int b = (int)(w % n_ring);
             const uint64_t o = w * window, in_win = std::min<uint64_t>(window, nb - o);
             const uint64_t len = std::min<uint64_t>(window + PW_LOOK, nb - o);
             const bool last = w + 1 == n_win, more = o + len < nb;
@@ -581,15 +609,7 @@ cellector_status parse_windowed(cellector_ctx *c, const FileBytes &fb, size_t da
         if (st == CELLECTOR_OK && e != hipSuccess) st = ctx_fail(c, CELLECTOR_EDEVICE, "parse: %s", hipGetErrorString(e));
         if (st == CELLECTOR_OK) *n_lines = line_base;
     }
-    if (up) (void)hipStreamSynchronize(up);
-    for (int b = 0; b < PW_NB; b++) {
-        if (ev_up[b]) (void)hipEventDestroy(ev_up[b]);
-        if (ev_free[b]) (void)hipEventDestroy(ev_free[b]);
-        if (pin[b]) (void)hipHostFree(pin[b]);
-        dev_free(dev[b]);
-    }
-    dev_free(seg);
-    if (up) (void)hipStreamDestroy(up);
+    if (up) (void)hipStreamSynchronize(up);  // (the buffers go on to the pair's other file)
     return st;
 }
 
@@ -698,17 +718,26 @@ cellector_status ingest_stage_mtx_device(cellector_ctx *c, MtxInput *in)
     // a multi-GB file goes through the device in windows (option parse_window forces a window size: tests); the token
     // arrays' capacity comes from the size line's entry count (a hint only: the reference never reads it)
     uint64_t n_a = 0, n_r = 0;
-    const uint64_t win = c->parse_window_opt > 0 ? (uint64_t)c->parse_window_opt : PW_WINDOW;
-    if (c->parse_window_opt > 0 || !fa.data || fa.size - off_a >= UP_MIN)
-        PCHK((parse_windowed<true>(c, fa, off_a, win, in->nnz_hint, &l1, &c1, &a, &n_a, bad)));
-    else
-        PCHK((parse_whole<true>(c, fa, off_a, &l1, &c1, &a, &n_a, bad)));
-    lap("alt file (upload + tokens)");
-    if (c->parse_window_opt > 0 || !fr.data || fr.size - off_r >= UP_MIN)
-        PCHK((parse_windowed<false>(c, fr, off_r, win, in->nnz_hint, (uint32_t **)nullptr, (uint32_t **)nullptr, &r, &n_r, bad + 1)));
-    else
-        PCHK((parse_whole<false>(c, fr, off_r, (uint32_t **)nullptr, (uint32_t **)nullptr, &r, &n_r, bad + 1)));
-    lap("ref file (upload + tokens)");
+    uint64_t win = c->parse_window_opt > 0 ? (uint64_t)c->parse_window_opt : PW_WINDOW;
+    if (win < 4 * NL_SEG) win = 4 * NL_SEG;
+    win &= ~(uint64_t)(NL_SEG - 1);
+    const bool win_a = c->parse_window_opt > 0 || !fa.data || fa.size - off_a >= PW_MIN;
+    const bool win_r = c->parse_window_opt > 0 || !fr.data || fr.size - off_r >= PW_MIN;
+    {
+        PwBuffers B;  // one ring of window buffers for both files
+        if (win_a || win_r) {
+            const uint64_t longest = std::max(win_a ? fa.size - off_a : 0, win_r ? fr.size - off_r : 0);
+            PCHK(B.make(c, win, (int)std::min<uint64_t>(PW_NB, std::max<uint64_t>(1, (longest + win - 1) / win))));
+        }
+        if (win_a) PCHK((parse_windowed<true>(c, fa, off_a, B, in->nnz_hint, &l1, &c1, &a, &n_a, bad)));
+        else PCHK((parse_whole<true>(c, fa, off_a, &l1, &c1, &a, &n_a, bad)));
+        lap("alt file (upload + tokens)");
+        if (win_r)
+            PCHK((parse_windowed<false>(c, fr, off_r, B, in->nnz_hint, (uint32_t **)nullptr, (uint32_t **)nullptr, &r, &n_r, bad + 1)));
+        else
+            PCHK((parse_whole<false>(c, fr, off_r, (uint32_t **)nullptr, (uint32_t **)nullptr, &r, &n_r, bad + 1)));
+        lap("ref file (upload + tokens)");
+    }
     const uint64_t n = std::min(n_a, n_r);  // izip!: stops at the shorter file
     e = hipMemcpy(h_bad, bad, sizeof h_bad, hipMemcpyDeviceToHost);
     if (e != hipSuccess) { cleanup(); return ctx_fail(c, CELLECTOR_EDEVICE, "parse: %s", hipGetErrorString(e)); }

@@ -66,7 +66,7 @@ cellector_status cellector_set_stream(cellector_ctx *ctx, void *hip_stream);
  * "side_lds" (engine 2, default -1: automatic residency throttle of the side-stream kernels),
  * "tile_groups" (engine 2, default 0: the number of locus-chunk groups of the tile kernel is chosen per matrix;
  * a multiple of 8 up to 64 forces it — set before ingest; results may differ in the last bit),
- * "parse_window" (default 0: a text file of 4 GB or more is uploaded and tokenised in 256 MB windows, a smaller
+ * "parse_window" (default 0: a text file of 1 GB or more is uploaded and tokenised in 256 MB windows, a smaller
  * one whole; a positive value forces windows of that many bytes — tests; lines of a windowed file may be 1 MB long),
  * "norm_zero" (default 1: a shard clears the other shards' slices of CELLECTOR_XCHG_NORM before it writes
  * its own, so that a SUM all-reduce completes the array; 0 when the caller all-gathers the slices). */
