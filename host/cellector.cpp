@@ -15,6 +15,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <unistd.h>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -542,6 +543,10 @@ int main(int argc, char **argv)
         sb += std::string(xoffset, ' ') + "|" + std::string(header.size() - 1, '-') + "|\n";
         printf("\n\n%s\n", sb.c_str());
     }
-    cellector_destroy(g.c);
-    return 0;
+    // Every output file is closed: leave without tearing the context down.  Handing ~150 GB of device memory back block
+    // by block (and destroying the host vectors) was half a second of the 1M x 200k run; the driver reclaims a dead
+    // process' memory in one go.
+    fflush(stdout);
+    fflush(stderr);
+    _exit(0);
 }
