@@ -413,7 +413,8 @@ __device__ __forceinline__ double ov_expected_rec(double alpha, double beta, uin
 #define OV_ROW 128
 #define OV_EOFF 64
 #define OV_REC 8  // the cell side's per-locus record: alpha, beta, E(5..8), pad = ONE 64-byte sector per overflow entry
-__global__ __launch_bounds__(256) void k_ovf_tables(uint64_t L, const double2 *__restrict__ ab, double *__restrict__ otab)
+__global__ __launch_bounds__(256) void k_ovf_tables(uint64_t L, const double2 *__restrict__ ab, const uint32_t *__restrict__ nmask,
+                                                    double *__restrict__ otab)
 {
     const uint64_t idx = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     const uint64_t l = idx / 3;
@@ -425,11 +426,14 @@ __global__ __launch_bounds__(256) void k_ovf_tables(uint64_t L, const double2 *_
         if (fam == 0) row[0] = -1.0;  // marks a masked locus
         return;
     }
+    // only as far as the largest tabulated total among the locus' overflow entries (nmask, static): the logs are the
+    // kernel's whole cost, and most loci stop at a total of 6 or 7 of the 17
+    const uint32_t m = nmask[l];
+    const int top = m ? 4 + (31 - __clz((int)m)) : 0;
     const double x0 = fam == 0 ? p.x : (fam == 1 ? p.y : p.x + p.y);
     double acc = 0.0;
     row[0] = 0.0;
-#pragma unroll
-    for (int i = 0; i < OV_NT - 1; i++) {
+    for (int i = 0; i < OV_NT - 1 && i < top; i++) {
         acc += log(x0 + (double)i);
         row[i + 1] = acc;
     }
@@ -1654,7 +1658,7 @@ static void launch_overflow_cell(cellector_ctx *c, hipStream_t st, const double2
 // locus side: the overflow entries' log-pmfs in by-locus order (ovf_lp), on stream `st`
 static void launch_overflow_locus_values(cellector_ctx *c, hipStream_t st, const double2 *ab)
 {
-    hipLaunchKernelGGL(k_ovf_tables, dim3(gcap(c->L * 3, 256, 0x7fffffffu)), dim3(256), 0, st, c->L, ab, c->ovf_tab);
+    hipLaunchKernelGGL(k_ovf_tables, dim3(gcap(c->L * 3, 256, 0x7fffffffu)), dim3(256), 0, st, c->L, ab, c->ovf_nmask, c->ovf_tab);
     hipLaunchKernelGGL(k_ovf_values, dim3(gcap(c->ovf_n, 256, 0x7fffffffu)), dim3(256), 0, st, c->ovf_n, c->ovc_locus, c->ovc_ent, ab,
                        c->lf, c->ovf_tab, c->ovf_lp);
 }
