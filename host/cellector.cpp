@@ -548,5 +548,9 @@ int main(int argc, char **argv)
     // process' memory in one go.
     fflush(stdout);
     fflush(stderr);
+    if (getenv("CELLECTOR_TEARDOWN")) {  // (a profiler's exit handlers, leak checkers: the orderly way out)
+        cellector_destroy(g.c);
+        return 0;
+    }
     _exit(0);
 }
