@@ -184,7 +184,7 @@ def main():
     n_loc = ce - cb
     info = g.engine_info()
     # Dominant kernel and the entries ONE launch of it processes on this rank:
-    #   engine 2: k_tile_ll, the regular entries (1 <= alt+ref <= 3); engine 1: k_cell_ll, all entries.
+    #   engine 2: k_tile_ll, the regular entries (1 <= alt+ref <= 4); engine 1: k_cell_ll, all entries.
     # Algorithmic bytes: 8 B/entry (u32 locus + u16 alt + u16 ref) + u64 row pointers
     #   + f64 LL and u32 loci-used out per cell + alpha,beta read once per locus.
     if args.engine == 2:

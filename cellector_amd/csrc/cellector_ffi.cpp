@@ -86,6 +86,9 @@ static void free_matrix(cellector_ctx *c)
     c->coo_n = 0; c->L = c->nnz = c->nloc = 0;
     c->state = cellector_ctx::ST_EMPTY;
     c->em_phase = 0; c->iteration = 0; c->have_iter = false; c->n_excluded_global = 0;
+    // nothing built ahead for the previous matrix survives a reload: the next em_begin must form alpha/beta and the
+    // tables itself (em_finish leaves tables_prebuilt set; the new matrix' table buffers are fresh allocations)
+    c->tables_prebuilt = false; c->prebuilt_expected = false; c->work_zeroed = false; c->ovf_locus_pending = false;
 }
 
 // the side stream gets the lowest priority the device offers: its kernels should only fill slots the main stream's
@@ -289,6 +292,8 @@ cellector_status cellector_set_option(cellector_ctx *c, const char *key, int64_t
     } else if (!strcmp(key, "engine")) {
         if (v != 1 && v != 2) return ctx_fail(c, CELLECTOR_EINVAL, "engine must be 1 (CSR/CSC kernels) or 2 (tiled)");
         if (c->em_phase != 0) return ctx_fail(c, CELLECTOR_EINVAL, "cannot switch engine inside an iteration");
+        if (v == 1 && c->state == cellector_ctx::ST_READY && !c->csc_ent && c->nnz)
+            return ctx_fail(c, CELLECTOR_EINVAL, "engine 1 needs the by-locus CSC, which an engine-2 ingest releases: set engine 1 before the ingest");
         if (v == 2 && c->state == cellector_ctx::ST_READY && !c->tiled_ready) {
             HIPCHK(c, hipSetDevice(c->device));
             if (c->n_masked_loci) return ctx_fail(c, CELLECTOR_EINVAL, "switch to engine 2 before any locus is masked");
@@ -435,7 +440,12 @@ cellector_status cellector_ingest_finish(cellector_ctx *c, uint64_t min_alt, uin
     HIPCHK(c, hipMemsetAsync(c->x_norm, 0, (need_norm ? need_norm : 1) * 8, c->stream));
     HIPCHK(c, hipMemsetAsync(c->x_locus, 0, need_locus * 8, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (c->engine == 2) CHK(tiled_build(c));
+    if (c->engine == 2) {
+        CHK(tiled_build(c));
+        // the packed by-locus CSC (8 B per entry: 16 GB at 2e9 entries) is only streamed by engine 1; engine 2 has built
+        // its compact CSC and overflow CSC from it.  Engine 1 must therefore be chosen BEFORE the ingest.
+        dev_free(c->csc_ent);
+    }
     if (timing) fprintf(stderr, "[timing]   tiled layouts           %8.3f s\n", lap_s(&t));
     dev_cache_trim();  // the ingest's big temporaries are done: hand the cached blocks back
     c->state = cellector_ctx::ST_READY;
@@ -670,6 +680,7 @@ cellector_status cellector_em_finish(cellector_ctx *c, cellector_iter_summary *o
         out->n_excluded = c->n_excluded_global;
         out->any_change = (out->n_new_excluded > 0 || out->n_rescued > 0) ? 1 : 0;  // main.rs:335
         out->n_loci_filtered = dc[0];
+        out->n_near_threshold = (uint64_t)cnt[LC_N_NEAR];
         out->median = c->last_median; out->iqr = c->last_iqr; out->threshold = c->last_thr;
     }
     return CELLECTOR_OK;

@@ -22,7 +22,9 @@
 
 // LOCUS exchange buffer layout (f64): 5 planes of L then 8 counters
 enum { LB_CONTRIB_MIN = 0, LB_CONTRIB_MAJ = 1, LB_CELLS_MIN = 2, LB_ALT_MIN = 3, LB_REF_MIN = 4, LB_PLANES = 5 };
-enum { LC_N_NEW = 0, LC_N_RESCUED = 1, LC_N_EXCLUDED = 2, LC_COUNTERS = 8 };
+enum { LC_N_NEW = 0, LC_N_RESCUED = 1, LC_N_EXCLUDED = 2, LC_N_NEAR = 3 /* cells within the near-tie band of the threshold */,
+       LC_COUNTERS = 8 };
+#define CELLECTOR_NEAR_TIE_REL 1e-9  // |norm - thr| <= this * max(1, |thr|) counts as a near-tie (cellector_iter_summary)
 // PASS1 exchange buffer layout (f64): 5 planes of total_loci
 enum { P1_CELLS_REF = 0, P1_CELLS_ALT = 1, P1_SUM_REF = 2, P1_SUM_ALT = 3, P1_ENTRIES = 4, P1_PLANES = 5 };
 

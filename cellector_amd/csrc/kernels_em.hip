@@ -106,38 +106,48 @@ __global__ __launch_bounds__(FLAG_THREADS) void k_flag(uint64_t n, const double 
     // a block takes a contiguous span of cells (a multiple of the block size), wave w of it the 64-cell pieces w, w+16, ...
     const uint64_t span = ((n + gridDim.x - 1) / gridDim.x + FLAG_THREADS - 1) / FLAG_THREADS * FLAG_THREADS;
     const uint64_t beg = min(n, (uint64_t)blockIdx.x * span), end = min(n, beg + span);
-    uint32_t c_new = 0, c_res = 0, c_exc = 0;
+    uint32_t c_new = 0, c_res = 0, c_exc = 0, c_near = 0;
+    // near-ties: the device arithmetic is a reformulation of the reference's (device_math.h), ~1e-11 away from it on a
+    // normalised log-likelihood; a cell this close to the threshold could fall on the other side of main.rs:330-332's
+    // strict `<` in the reference.  Counted, reported in the summary, never acted upon.
+    const double near_tol = CELLECTOR_NEAR_TIE_REL * fmax(1.0, fabs(thr));
     for (uint64_t i = beg + threadIdx.x; i < end; i += FLAG_THREADS) {
-        const bool nf = norm[i] < thr;
+        const double v = norm[i];
+        const bool nf = v < thr;
         const bool of = old_flags[i] != 0;
         new_flags[i] = nf ? 1 : 0;
         c_new += (nf && !of) ? 1u : 0u;
         c_res += (of && !nf) ? 1u : 0u;
         c_exc += nf ? 1u : 0u;
+        c_near += fabs(v - thr) <= near_tol ? 1u : 0u;
     }
     // one f64 atomic per BLOCK and counter (integers: exact and order independent; atomics on one address serialise)
-    __shared__ uint32_t s_new[FLAG_THREADS / 64], s_res[FLAG_THREADS / 64];
+    __shared__ uint32_t s_new[FLAG_THREADS / 64], s_res[FLAG_THREADS / 64], s_near[FLAG_THREADS / 64];
     c_new = wave_sum_u32(c_new);
     c_res = wave_sum_u32(c_res);
     c_exc = wave_sum_u32(c_exc);
+    c_near = wave_sum_u32(c_near);
     if ((threadIdx.x & 63) == 0) {
         s_new[threadIdx.x >> 6] = c_new;
         s_res[threadIdx.x >> 6] = c_res;
         s_wave[threadIdx.x >> 6] = c_exc;
+        s_near[threadIdx.x >> 6] = c_near;
     }
     __syncthreads();
     // The members of the new exclusion set as a list (engine 2's minority-driven locus tally): ONE atomic per block
     // reserves the block's slots, then a second walk over the span (L2-hot) fills them.  The list's order depends on
     // the block order only through the bases, and only order-independent integer tallies are derived from it.
     if (threadIdx.x == 0) {
-        uint32_t tot = 0, t_new = 0, t_res = 0;
+        uint32_t tot = 0, t_new = 0, t_res = 0, t_near = 0;
         for (int w = 0; w < FLAG_THREADS / 64; w++) {
             const uint32_t x = s_wave[w];
             s_wave[w] = tot;
             tot += x;
             t_new += s_new[w];
             t_res += s_res[w];
+            t_near += s_near[w];
         }
+        if (t_near) atomicAdd(&counters[LC_N_NEAR], (double)t_near);
         if (t_new) atomicAdd(&counters[LC_N_NEW], (double)t_new);
         if (t_res) atomicAdd(&counters[LC_N_RESCUED], (double)t_res);
         if (tot) atomicAdd(&counters[LC_N_EXCLUDED], (double)tot);

@@ -358,13 +358,17 @@ cellector_status upload_text(cellector_ctx *c, const FileBytes &fb, size_t data_
     dt->n = fb.size - data_off;
     // a final line without '\n' still counts (BufRead::lines); normalise by treating the end of data as a terminator
     CHK(dev_alloc(c, &dt->text, dt->n + 16));
-    HIPCHK(c, hipMemset(dt->text + dt->n, '\n', 16));
+    // (everything below is ordered on the ctx's stream, which may be a non-blocking one: no null-stream calls)
+    HIPCHK(c, hipMemsetAsync(dt->text + dt->n, '\n', 16, c->stream));
     if (dt->n < UP_MIN) {  // pinning the two buffers costs ~0.1 s: only worth it for multi-GB files
         const size_t piece = 1ull << 30;
         for (size_t o = 0; o < dt->n; o += piece)
-            HIPCHK(c, hipMemcpy(dt->text + o, fb.data + data_off + o, std::min(piece, (size_t)dt->n - o), hipMemcpyHostToDevice));
+            HIPCHK(c, hipMemcpyAsync(dt->text + o, fb.data + data_off + o, std::min(piece, (size_t)dt->n - o), hipMemcpyHostToDevice,
+                                     c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
         return CELLECTOR_OK;
     }
+    HIPCHK(c, hipStreamSynchronize(c->stream));  // (the padding is in place before the upload stream's copies are consumed)
     uint8_t *pin[2] = {nullptr, nullptr};
     hipEvent_t ev[2] = {nullptr, nullptr};
     hipStream_t up = nullptr;
@@ -712,8 +716,9 @@ cellector_status ingest_stage_mtx_device(cellector_ctx *c, MtxInput *in)
     PCHK(dev_alloc(c, &bad, 3)); PCHK(dev_alloc(c, &flags, 4));
     unsigned long long h_bad[3] = {~0ull, ~0ull, ~0ull};
     uint32_t h_flags[4] = {0, 0, 0, 0};
-    hipError_t e = hipMemcpy(bad, h_bad, sizeof h_bad, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(flags, h_flags, sizeof h_flags, hipMemcpyHostToDevice);
+    hipError_t e = hipMemcpyAsync(bad, h_bad, sizeof h_bad, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(flags, h_flags, sizeof h_flags, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess) { cleanup(); return ctx_fail(c, CELLECTOR_EDEVICE, "parse: %s", hipGetErrorString(e)); }
     // a multi-GB file goes through the device in windows (option parse_window forces a window size: tests); the token
     // arrays' capacity comes from the size line's entry count (a hint only: the reference never reads it)
@@ -739,7 +744,8 @@ cellector_status ingest_stage_mtx_device(cellector_ctx *c, MtxInput *in)
         lap("ref file (upload + tokens)");
     }
     const uint64_t n = std::min(n_a, n_r);  // izip!: stops at the shorter file
-    e = hipMemcpy(h_bad, bad, sizeof h_bad, hipMemcpyDeviceToHost);
+    e = hipMemcpyAsync(h_bad, bad, sizeof h_bad, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess) { cleanup(); return ctx_fail(c, CELLECTOR_EDEVICE, "parse: %s", hipGetErrorString(e)); }
     {   // (a line beyond the shorter file is never read by the reference: only failures among the first n count)
         const unsigned long long first = std::min(h_bad[0], h_bad[1]);
@@ -752,8 +758,11 @@ cellector_status ingest_stage_mtx_device(cellector_ctx *c, MtxInput *in)
     if (!all_cells) PCHK(dev_alloc(c, &keep, n + 1));
     hipLaunchKernelGGL(k_pair_check, dim3(pgrid(n + 1)), dim3(PB), 0, c->stream, n, l1, c1, a, r, c->total_loci, c->total_cells,
                        c->cell_begin, c->cell_end, keep, bad + 2, flags, flags + 1);
-    e = hipMemcpy(h_bad, bad, sizeof h_bad, hipMemcpyDeviceToHost);
-    if (e == hipSuccess) e = hipMemcpy(h_flags, flags, sizeof h_flags, hipMemcpyDeviceToHost);
+    // the validation result is read BEHIND k_pair_check on the ctx's stream (a caller-supplied non-blocking stream does
+    // not order against null-stream copies: the range check could be read before the kernel ran)
+    e = hipMemcpyAsync(h_bad, bad, sizeof h_bad, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(h_flags, flags, sizeof h_flags, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess) { cleanup(); return ctx_fail(c, CELLECTOR_EDEVICE, "parse: %s", hipGetErrorString(e)); }
     if (h_bad[2] != ~0ull) {
         cleanup();

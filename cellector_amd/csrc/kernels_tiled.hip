@@ -1835,9 +1835,9 @@ cellector_status tiled_locus_pass(cellector_ctx *c)
 #define LAUNCH_LS(INLDS, EBV, GRID, LDSB)                                                                              \
     hipLaunchKernelGGL((k_locus_stats2<INLDS, EBV>), dim3(GRID), dim3(LS_THREADS), LDSB, c->stream, c->L, words, c->c4_ptr, \
                        c->c4_ent, c->flag_bits, c->hist_min, c->locus_mode, c->nloc, c->d_counters + DC_N_MIN, c->lr_sub)
-    if (c->locus_mode == 2) {
-        // minority-driven form forced: nothing to stream
-    } else if (lds <= 128 * 1024) {
+    // (a forced minority-driven form, locus_mode 2, still launches the streamed kernel: it returns at once unless the
+    //  exclusion set is too large for that form's 16-bit counters, the one case the device predicate overrides the option)
+    if (lds <= 128 * 1024) {
         if (c->c4_bits == 24) {
             // the whole 2^20-cell bitmask: a padding entry (cell = all ones) then reads inside the allocation
             const int lb = 128 * 1024;

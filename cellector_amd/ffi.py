@@ -69,7 +69,7 @@ class EngineInfo(C.Structure):
 
 class IterSummary(C.Structure):
     _fields_ = [("any_change", C.c_int32), ("n_new_excluded", _u64), ("n_rescued", _u64), ("n_excluded", _u64),
-                ("n_loci_filtered", _u64), ("median", _d), ("iqr", _d), ("threshold", _d)]
+                ("n_loci_filtered", _u64), ("median", _d), ("iqr", _d), ("threshold", _d), ("n_near_threshold", _u64)]
 
 
 class CellectorError(RuntimeError):
@@ -139,6 +139,10 @@ class Cellector:
     # ---- configuration
     def set_option(self, key, value):
         self._ck(self._lib.cellector_set_option(self.h, key.encode(), int(value)))
+
+    def set_stream(self, stream):
+        """hipStream_t as an integer (e.g. torch.cuda.current_stream().cuda_stream); 0 / None = the null stream"""
+        self._ck(self._lib.cellector_set_stream(self.h, C.c_void_p(stream or None)))
 
     def set_shard(self, cell_begin, cell_end):
         self._ck(self._lib.cellector_set_shard(self.h, int(cell_begin), int(cell_end)))

@@ -368,6 +368,11 @@ int main(int argc, char **argv)
                (unsigned long long)s.n_new_excluded, (unsigned long long)s.n_rescued, (unsigned long long)(iteration + 1));
         printf("median normalized log likelihood %s with interquartile range %s, threshold %s\n", fmt(s.median).c_str(),
                fmt(s.iqr).c_str(), fmt(s.threshold).c_str());
+        if (s.n_near_threshold)  // stderr only: stdout stays byte-compatible with main.rs:338-339
+            fprintf(stderr, "warning: iteration %llu: %llu cell(s) within 1e-9 (relative) of the threshold %s; the device's "
+                            "log-pmf arithmetic differs from the reference's by ~1e-11, so their anomaly flag may differ from "
+                            "the reference's\n", (unsigned long long)(iteration + 1), (unsigned long long)s.n_near_threshold,
+                    fmt(s.threshold).c_str());
         g.ck(cellector_iter_cell_outputs(g.c, ll.data(), ell.data(), nloci.data(), norm.data()), "cell outputs");
         g.ck(cellector_iter_locus_outputs(g.c, c_min.data(), c_maj.data(), n_min.data(), n_maj.data(), a_min.data(),
                                           r_min.data(), a_maj.data(), r_maj.data()), "locus outputs");

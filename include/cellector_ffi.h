@@ -54,7 +54,8 @@ cellector_status cellector_set_stream(cellector_ctx *ctx, void *hip_stream);
  * the engine's dominant kernel — each event pair idles the queue for a few microseconds),
  * "keep_coo" (default 1: keep the staged all-loci COO for cellector_final_allele_tallies),
  * "engine" (default 2: table-driven passes over the tiled 16-bit layout; 1: CSR/CSC kernels that
- * evaluate every entry's log-pmf — same results within rounding, kept for A/B checks),
+ * evaluate every entry's log-pmf — same results within rounding, kept for A/B checks; choose it before the
+ * ingest: an engine-2 ingest releases the packed by-locus CSC that only engine 1 streams),
  * "compact_bits" (default 0: the locus pass stores 24-bit entries when the shard has <= 2^20 cells,
  * else 32-bit; 32 forces the wide form — set before ingest),
  * "locus_mode" (engine 2, default 0: per iteration the device picks how the per-locus minority counts
@@ -144,6 +145,12 @@ typedef struct {
     uint64_t n_excluded;               /* |new exclusion set| over all shards                    */
     uint64_t n_loci_filtered;          /* loci newly masked by the -80 filter (main.rs:444-447)  */
     double median, iqr, threshold;     /* main.rs:325-329                                        */
+    /* Not in the reference: cells (all shards) with |normalised LL - threshold| <= 1e-9 * max(1, |threshold|).
+     * The device evaluates log_beta_binomial_pmf as an exact product ratio, ~1e-11 away from the reference's
+     * ln_gamma differences (stats.rs:41-53) on a normalised LL; such a cell could fall on the other side of
+     * main.rs:330-332's strict `<` in the reference.  Non-zero = the bit-identical-assignment claim does not
+     * cover those cells of this iteration.  host/cellector prints one stderr warning. */
+    uint64_t n_near_threshold;
 } cellector_iter_summary;
 
 /* phase A: init_alpha_betas (main.rs:598-611) from the previous exclusion set's tallies, then
@@ -196,7 +203,7 @@ cellector_status cellector_final_allele_tallies(cellector_ctx *ctx, uint64_t *al
 /* layout facts of the loaded shard (benchmark accounting) */
 typedef struct {
     uint64_t engine;
-    uint64_t nnz_regular;   /* entries with 1 <= alt+ref <= 3: handled by table lookup in the tiled passes */
+    uint64_t nnz_regular;   /* entries with 1 <= alt+ref <= 4: handled by table lookup in the tiled passes */
     uint64_t nnz_overflow;  /* the rest: evaluated individually                                           */
     uint64_t tile_bytes;    /* bytes of the tiled cell-pass layout                                        */
     uint64_t cell_blocks, locus_chunks, chunk_groups;

@@ -32,5 +32,5 @@ def test_library_loads_and_reports_version(hip_lib_path):
 
 def test_status_struct_layouts():
     assert ctypes.sizeof(ffi.Dims) == 48
-    assert ctypes.sizeof(ffi.IterSummary) == 64
-    assert ffi.IterSummary.median.offset == 40
+    assert ctypes.sizeof(ffi.IterSummary) == 72
+    assert ffi.IterSummary.median.offset == 40 and ffi.IterSummary.n_near_threshold.offset == 64

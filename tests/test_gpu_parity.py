@@ -64,8 +64,15 @@ def _check_iteration(g, o, sg, so):
     np.testing.assert_allclose(cg["expected_ll"], co["expected_ll"], rtol=0, atol=LL_ATOL)
     np.testing.assert_allclose(cg["normalized"], co["normalized"], rtol=0, atol=1e-9)
     np.testing.assert_allclose([sg.median, sg.iqr, sg.threshold], [so.median, so.iqr, so.threshold], rtol=0, atol=1e-9)
+    # the product's own near-tie report (cellector_iter_summary.n_near_threshold): the same IEEE expression on the
+    # device's values must give the same count, and any cell the oracle sees on the threshold must be reported
+    tol = 1e-9 * max(1.0, abs(sg.threshold))
+    assert sg.n_near_threshold == int((np.abs(cg["normalized"] - sg.threshold) <= tol).sum())
+    if (np.abs(co["normalized"] - so.threshold) < 0.9e-9).any():
+        assert sg.n_near_threshold > 0, "the oracle sees cells on the threshold, the product reported none"
     near = np.abs(co["normalized"] - so.threshold) < 1e-9
     assert not near.any(), f"near-tie cells at the threshold: {np.nonzero(near)[0]}"
+    assert sg.n_near_threshold == 0
     assert np.array_equal(g.excluded(), o.excluded())
     assert (sg.any_change, sg.n_new_excluded, sg.n_rescued) == (so.any_change, so.n_new_excluded, so.n_rescued)
     assert sg.n_excluded == int(o.excluded().sum())
@@ -300,6 +307,58 @@ def test_edge_counts_and_empty_cells(mods):
     g.close()
 
 
+def test_near_ties_are_reported(mods):
+    """Constructed tie: every cell carries the same entries, so all normalised LLs are equal, Q1 = Q3, and the threshold
+    sits exactly on every cell (strict `<`, main.rs:330-332: nobody is excluded).  The reference and the device differ
+    by ~1e-11 there, so which side such a cell falls on is not covered by the parity claim: the summary must say so."""
+    L, N = 40, 50
+    lo = np.repeat(np.arange(L, dtype=np.uint32), N)
+    ce = np.tile(np.arange(N, dtype=np.uint32), L)
+    al = np.ones(L * N, np.uint32)
+    re = np.ones(L * N, np.uint32)
+    g = mods["Cellector"](0)
+    g.load_coo(L, N, lo, ce, al, re)
+    o = mods["ob"].Oracle.from_coo(L, N, lo, ce, al, re)
+    sg, so = g.em_iteration(5.0), o.em_iteration(5.0)
+    assert sg.iqr == 0.0 and sg.n_excluded == 0 and not sg.any_change
+    assert sg.n_near_threshold == N
+    assert abs(sg.threshold - so.threshold) < 1e-9
+    # one cell pushed well below: it is excluded and no longer near; the others still tie with the threshold
+    al2 = al.copy(); re2 = re.copy()
+    al2[ce == 7] = 4; re2[ce == 7] = 0
+    g.load_coo(L, N, lo, ce, al2, re2)
+    sg = g.em_iteration(5.0)
+    assert sg.n_excluded == 1 and g.excluded()[7] == 1 and sg.n_near_threshold == N - 1
+    g.close(); o.close()
+
+
+def test_context_reload_starts_clean(mods):
+    """A ctx that ran iterations on one matrix and is then loaded with another must not carry tables built ahead for the
+    old one (em_finish queues the next iteration's k_build_tables): the second run must equal a fresh ctx and the oracle."""
+    la, ca, aa, ra = mods["synth"].generate_coo(900, 700, 0.12, seed=5, minority_fraction=0.1)
+    lb, cb, ab_, rb = mods["synth"].generate_coo(1300, 500, 0.1, seed=6, minority_fraction=0.07)
+    g = mods["Cellector"](0)
+    g.load_coo(900, 700, la, ca, aa, ra)
+    for _ in range(3):
+        g.em_iteration(5.0)                      # leaves tables prebuilt for iteration 4 of matrix A
+    g.load_coo(1300, 500, lb, cb, ab_, rb)      # same ctx, new matrix
+    f = mods["Cellector"](0)
+    f.load_coo(1300, 500, lb, cb, ab_, rb)
+    o = mods["ob"].Oracle.from_coo(1300, 500, lb, cb, ab_, rb)
+    _check_matrix(g, o)
+    for _ in range(30):
+        sg, sf, so = g.em_iteration(5.0), f.em_iteration(5.0), o.em_iteration(5.0)
+        _check_iteration(g, o, sg, so)
+        cg, cf = g.cell_outputs(), f.cell_outputs()
+        for k in cg:
+            assert np.array_equal(cg[k], cf[k]), k
+        assert (sg.threshold, sg.n_excluded) == (sf.threshold, sf.n_excluded)
+        if not so.any_change:
+            break
+    _check_posteriors(mods, g, o)
+    g.close(); f.close(); o.close()
+
+
 def test_locus_filter_triggers(mods):
     """A locus where the minority population is fixed for the other allele with deep coverage contributes far
     below -80 per minority cell and must be masked from the next iteration on (main.rs:444-447)."""
@@ -532,6 +591,48 @@ def test_mtx_text_contract_on_device(mods, tmp_path):
     with pytest.raises(mods["ffi"].CellectorError, match="size line"):
         g.load_mtx(str(hdr), str(hdr), 1, 1)
     g.close()
+
+
+def test_text_ingest_on_a_non_blocking_stream(mods, tmp_path):
+    """cellector_set_stream documents torch's current stream; inside torch.cuda.stream(s) that is a NON-blocking stream,
+    which null-stream copies do not order against.  The parser's validation (index 0, out-of-range indices, counts above
+    65535) must be read behind its kernel on that stream: a malformed file must still be refused, a valid one must load
+    to the same matrix as on the null stream — through the whole-file and the windowed path."""
+    if mods["engine"] != 2:
+        pytest.skip("ingest path: one engine is enough")
+    import torch
+    L, N = 600, 500
+    lo, ce, al, re = mods["synth"].generate_coo(L, N, 0.08, seed=31)
+    a_path, r_path = mods["synth"].write_mtx_pair(str(tmp_path), L, N, lo, ce, al, re)
+    ref = mods["Cellector"](0)
+    ref.load_mtx(a_path, r_path, 2, 2)
+    rr, er = ref.csr_rows(0, N)
+    s2 = ref.em_iteration(5.0)
+    side = torch.cuda.Stream(device=0)
+    many = "".join(f"1 {1 + i % 3} 1\n" for i in range(3000))
+    bad_cases = {"index0": many + "0 1 1\n", "locus_range": many + "3 1 1\n", "cell_range": many + "1 4 1\n",
+                 "count_range": many + "1 1 70000\n"}
+    with torch.cuda.stream(side):
+        for window in (0, 4096):
+            g = mods["Cellector"](0)
+            g.set_stream(torch.cuda.current_stream().cuda_stream)
+            assert torch.cuda.current_stream().cuda_stream == side.cuda_stream != 0
+            if window:
+                g.set_option("parse_window", window)
+            g.load_mtx(a_path, r_path, 2, 2)
+            rg, eg = g.csr_rows(0, N)
+            assert np.array_equal(rg, rr) and np.array_equal(eg, er)
+            assert np.array_equal(g.locus_counts(), ref.locus_counts())
+            s1 = g.em_iteration(5.0)
+            assert (s1.threshold, s1.n_excluded) == (s2.threshold, s2.n_excluded)
+            for name, body in bad_cases.items():
+                bad = tmp_path / f"nb_{name}.mtx"
+                bad.write_text("%%MatrixMarket\n%\n2 3 0\n" + body)
+                with pytest.raises(mods["ffi"].CellectorError) as ei:
+                    g.load_mtx(str(bad), str(bad), 1, 1)
+                assert ei.value.status == 1 and "entry 3000" in str(ei.value), (name, str(ei.value))
+            g.close()
+    ref.close()
 
 
 def test_windowed_text_parse_equals_whole_file_parse(mods, tmp_path):
