@@ -127,8 +127,17 @@ def test_full_size_sampled_parity_and_properties(name, N, L, oracle_lib, hip_lib
     dm = g.dims()
     assert (dm.total_cells, dm.total_loci) == (N, L) and dm.loci_used > 0.9 * L
     lc = g.locus_counts()
-    n_s = 3000
-    rp, ent = g.csr_rows(0, n_s)
+    # the oracle's sample: row ranges spread over the whole matrix — the first 1024-cell block, ranges that straddle
+    # block and 4-block column boundaries at several depths (different chunk-group work items), the middle, and the
+    # ragged last block
+    last_block = (N - 1) // 1024 * 1024
+    ranges = [(0, 700), (1000, 1400), (4090, 4500), (N // 5 + 333, N // 5 + 333 + 500), (N // 2 - 300, N // 2 + 300),
+              (2 * N // 3 + 17, 2 * N // 3 + 17 + 400), (last_block - 200, last_block + 100), (max(last_block + 100, N - 300), N)]
+    sel = np.concatenate([np.arange(a, b) for a, b in ranges])
+    assert len(sel) == len(np.unique(sel)) and sel[-1] == N - 1
+    rps, ents = zip(*(g.csr_rows(a, b) for a, b in ranges))
+    rp = np.concatenate([[0], np.cumsum(np.concatenate([np.diff(r) for r in rps]))]).astype(np.uint64)
+    ent = np.concatenate(ents)
     o = ob.Oracle.from_csr(dm.loci_used, rp, ent, lc)
     ob.set_threads(ob.host_threads())
     try:
@@ -140,9 +149,9 @@ def test_full_size_sampled_parity_and_properties(name, N, L, oracle_lib, hip_lib
             s = g.em_iteration(5.0)
             cg = g.cell_outputs()
             ll_o, ell_o, nl_o = o.cell_log_likelihoods(alpha, beta, mask)
-            np.testing.assert_allclose(cg["ll"][:n_s], ll_o, rtol=0, atol=LL_ATOL)
-            np.testing.assert_allclose(cg["expected_ll"][:n_s], ell_o, rtol=0, atol=LL_ATOL)
-            assert np.array_equal(cg["loci_used"][:n_s], nl_o)
+            np.testing.assert_allclose(cg["ll"][sel], ll_o, rtol=0, atol=LL_ATOL)
+            np.testing.assert_allclose(cg["expected_ll"][sel], ell_o, rtol=0, atol=LL_ATOL)
+            assert np.array_equal(cg["loci_used"][sel], nl_o)
             # threshold from exact order statistics of ALL cells (numpy sort as the independent check)
             srt = np.sort(cg["normalized"])
             k = N // 2
@@ -181,12 +190,12 @@ def test_full_size_sampled_parity_and_properties(name, N, L, oracle_lib, hip_lib
         l_min = o.cell_log_likelihoods(a1, b1)[0]
         l_maj = o.cell_log_likelihoods(a2, b2)[0]
         l_dbl = o.cell_log_likelihoods(a3, b3)[0]
-        np.testing.assert_allclose(pg["ll_minority"][:n_s], l_min, rtol=0, atol=LL_ATOL)
-        np.testing.assert_allclose(pg["ll_majority"][:n_s], l_maj, rtol=0, atol=LL_ATOL)
+        np.testing.assert_allclose(pg["ll_minority"][sel], l_min, rtol=0, atol=LL_ATOL)
+        np.testing.assert_allclose(pg["ll_majority"][sel], l_maj, rtol=0, atol=LL_ATOL)
         num = lp_min + l_min
         den = _lse(_lse(num, lp_maj + l_maj), lp_dbl + l_dbl)
-        np.testing.assert_allclose(pg["posterior"][:n_s], np.exp(num - den), rtol=0, atol=POST_ATOL)
-        np.testing.assert_allclose(pg["doublet_posterior"][:n_s], np.exp(lp_dbl + l_dbl - den), rtol=0, atol=POST_ATOL)
+        np.testing.assert_allclose(pg["posterior"][sel], np.exp(num - den), rtol=0, atol=POST_ATOL)
+        np.testing.assert_allclose(pg["doublet_posterior"][sel], np.exp(lp_dbl + l_dbl - den), rtol=0, atol=POST_ATOL)
     finally:
         ob.set_threads(1)
         o.close()

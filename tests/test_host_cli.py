@@ -38,6 +38,36 @@ def test_rust_display_model():
     assert rust_display(0.1 + 0.2) == "0.30000000000000004" and rust_display(float("inf")) == "inf"
 
 
+def pretty_print(assignment_gt_counts, gt_counts):
+    """The confusion table of main.rs:177-226, built string for string (what `println!("\\n\\n{}", string_build)` prints,
+    without that final newline).  Ground truths are listed by descending count (ties: hash order in the reference — the
+    tests use ground truths with distinct counts)."""
+    count_vec = sorted(gt_counts.items(), key=lambda kv: -kv[1])
+    first_header, header = "cellector assignment   ", "      0      1      unassigned\n"
+    sb = first_header + header
+    xoffset = max(3, len(first_header) + 2)
+    sb += "cell_hashing" + " " * max(0, xoffset - 12) + "|" + "-" * max(0, len(header) - 1) + "|\n"
+    for gt, _ in count_vec:
+        xoffset = max(xoffset, len(gt) + 3)
+        c0, c1, un = (str(assignment_gt_counts.get(k, {}).get(gt, 0)) for k in ("0", "1", "unassigned"))
+        sb += gt + " " * max(0, xoffset - max(0, len(gt) - 1))
+        sb += " |  " + c0 + " " * max(0, 4 - len(c0))
+        sb += " |  " + c1 + " " * max(0, 4 - len(c1))
+        sb += " |  " + un + " " * max(0, 12 - len(un)) + "|\n"
+    sb += " " * xoffset + "|" + "-" * max(0, len(header) - 1) + "|\n"
+    return "\n\n" + sb
+
+
+def test_pretty_print_model():
+    t = pretty_print({"0": {"minority": 7}, "1": {"majority": 12345, "minority": 1}, "unassigned": {"majority": 2}},
+                     {"majority": 12347, "minority": 8})
+    assert t == ("\n\ncellector assignment         0      1      unassigned\n"
+                 "cell_hashing             |------------------------------|\n"
+                 "majority                   |  0    |  12345 |  2           |\n"
+                 "minority                   |  7    |  1    |  0           |\n"
+                 "                         |------------------------------|\n")
+
+
 def test_cli_usage_errors(host_bin):
     r = subprocess.run([host_bin, "--help"], capture_output=True, text=True)
     assert r.returncode == 0 and "--output_directory" in r.stdout and "-r, --ref <ref>" in r.stdout
@@ -99,7 +129,7 @@ def test_full_run_matches_oracle(host_bin, oracle_lib, tmp_path, gz):
         np.testing.assert_allclose(got[:, 1], co["expected_ll"], rtol=0, atol=1e-7)
         assert np.array_equal(got[:, 2], co["loci_used"])
         assert rows[1][0] == "0" and rows[1][1] == "CELL0000000-1" and rows[1][2] in ("majority", "minority", "doublet")
-        for row in rows[1:50]:
+        for row in rows[1:]:  # every float of every row is in Rust's `{}` form
             for x in row[3:6]:
                 assert rust_display(float(x)) == x, x
         thr = open(os.path.join(out, f"iteration_{it}_threshold.tsv")).read()
@@ -113,6 +143,8 @@ def test_full_run_matches_oracle(host_bin, oracle_lib, tmp_path, gz):
         assert np.all(np.diff(per_cell) >= 0)  # ascending log_likelihood_minority_per_cell (argsort, main.rs:440,453)
         for row in rows[1:]:
             l = pos_of[int(row[0])]
+            for x in row[3:7] + row[9:11] + row[15:17]:
+                assert rust_display(float(x)) == x, x
             assert row[1] == f"chr{1 + int(row[0]) % 22}" and row[2] == str(1000 + 37 * int(row[0]))
             assert float(row[3]) == pytest.approx(lo_["contrib_min"][l], abs=1e-7) and row[5] == row[3] and row[6] == row[4]
             assert float(row[4]) == pytest.approx(lo_["contrib_maj"][l], abs=1e-6)
@@ -132,6 +164,8 @@ def test_full_run_matches_oracle(host_bin, oracle_lib, tmp_path, gz):
                        "ground_truth_assignment"]
     co = o.cell_outputs()
     for c, row in enumerate(rows[1:]):
+        for x in (row[3], row[6], row[7]):
+            assert rust_display(float(x)) == x, x
         assert row[0] == f"CELL{c:07d}-1" and row[1] == names[pa[c]] and row[2] == str(aa[c])
         assert float(row[3]) == pytest.approx(co["normalized"][c], abs=1e-9) and int(row[4]) == int(co["loci_used"][c])
         assert abs(int(row[5]) - int(q[c])) <= 1
@@ -139,11 +173,15 @@ def test_full_run_matches_oracle(host_bin, oracle_lib, tmp_path, gz):
         assert float(row[7]) == pytest.approx(po["ll_minority"][c], abs=1e-7)
     assert {"0", "1"} <= {row[1] for row in rows[1:]}
     # confusion table on stdout (main.rs:177-226)
-    tail = r.stdout.split("\n\n\n")[-1]
-    assert tail.startswith("cellector assignment         0      1      unassigned\ncell_hashing")
-    maj_line = [ln for ln in tail.splitlines() if ln.startswith("majority")][0]
-    n_maj1 = sum(1 for row in rows[1:] if row[8] == "majority" and row[1] == "1")
-    assert f"|  {n_maj1}" in maj_line
+    agc, gtc = {}, {}
+    for row in rows[1:]:
+        agc.setdefault(row[1], {}).setdefault(row[8], 0)
+        agc[row[1]][row[8]] += 1
+        gtc[row[8]] = gtc.get(row[8], 0) + 1
+    assert len(set(gtc.values())) == len(gtc) == 3  # distinct counts: the table's row order is defined
+    table = pretty_print(agc, gtc) + "\n"  # println!
+    assert r.stdout.endswith(table), (r.stdout[-600:], table)  # byte for byte
+    assert r.stdout.count("\n\n\ncellector assignment") == 1
     # cellector.vcf (Appendix C.8)
     tallies = oracle_lib.final_tallies_coo(L, *coo, o.excluded())
     vl = open(os.path.join(out, "cellector.vcf")).read().splitlines()
