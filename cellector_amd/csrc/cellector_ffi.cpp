@@ -6,12 +6,14 @@
 #include <cstdio>
 #include <cstring>
 
+#include <algorithm>
 #include <chrono>
 #include <vector>
 #include <unordered_map>
 #include <mutex>
 
 #include "ctx.h"
+#include "multi.h"
 
 cellector_status ctx_fail(const cellector_ctx *c, cellector_status s, const char *fmt, ...)
 {
@@ -227,10 +229,52 @@ cellector_status cellector_create(cellector_ctx **out, int device_id)
     return CELLECTOR_OK;
 }
 
+cellector_status cellector_device_count(int *out)
+{
+    if (!out) return CELLECTOR_EINVAL;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); n = 0; }
+    *out = n;
+    return CELLECTOR_OK;
+}
+
+cellector_status cellector_create_multi(cellector_ctx **out, const int *device_ids, int n_devices)
+{
+    if (!out || !device_ids || n_devices < 1 || n_devices > CELLECTOR_MAX_SHARDS) return CELLECTOR_EINVAL;
+    *out = nullptr;
+    if (n_devices == 1) return cellector_create(out, device_ids[0]);  // a plain single-shard ctx: nothing to exchange
+    return multi_create(out, device_ids, n_devices);
+}
+
+cellector_status cellector_comm_unique_id(void *out_128_bytes)
+{
+    if (!out_128_bytes) return CELLECTOR_EINVAL;
+    const char *why = nullptr;
+    const int st = comm_rccl_unique_id(out_128_bytes, &why);
+    if (st != CELLECTOR_OK) fprintf(stderr, "cellector_comm_unique_id: %s\n", why ? why : "RCCL error");
+    return (cellector_status)st;
+}
+
+cellector_status cellector_comm_init_rank(cellector_ctx *c, const void *unique_id_128, int n_ranks, int rank)
+{
+    if (!c || !unique_id_128) return CELLECTOR_EINVAL;
+    REQUIRE(c, !c->multi, "a multi-device ctx has its communicator already");
+    REQUIRE(c, c->state == cellector_ctx::ST_EMPTY, "attach the communicator before the ingest");
+    REQUIRE(c, !comm_active(c->comm), "ctx already has a communicator");
+    REQUIRE(c, n_ranks >= 1 && rank >= 0 && rank < n_ranks, "bad rank / rank count");
+    // (a one-rank communicator is made only on request: CELLECTOR_COMM_SELFTEST runs the RCCL calls of the sharded path on one GPU)
+    if (n_ranks == 1 && !getenv("CELLECTOR_COMM_SELFTEST")) return CELLECTOR_OK;
+    c->norm_zero = false;  // the NORM slices are all-gathered inside the library
+    return (cellector_status)comm_rccl_init_rank(c, unique_id_128, n_ranks, rank);
+}
+
 void cellector_destroy(cellector_ctx *c)
 {
     if (!c) return;
+    if (c->multi) { multi_destroy(c); return; }
     (void)hipSetDevice(c->device);
+    if (c->stream && c->owns_stream) (void)hipStreamSynchronize(c->stream);
+    comm_destroy(c);
     if (c->side) (void)hipStreamSynchronize(c->side);
     timer_collect(c);
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
@@ -240,6 +284,7 @@ void cellector_destroy(cellector_ctx *c)
     dev_free(c->sel_list);
     if (c->h_sel) (void)hipHostFree(c->h_sel);
     if (c->side) (void)hipStreamDestroy(c->side);
+    if (c->stream && c->owns_stream) (void)hipStreamDestroy(c->stream);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->ev_join2) (void)hipEventDestroy(c->ev_join2);
@@ -253,6 +298,8 @@ const char *cellector_last_error(const cellector_ctx *c) { return c ? c->err.c_s
 cellector_status cellector_set_stream(cellector_ctx *c, void *s)
 {
     if (!c) return CELLECTOR_EINVAL;
+    if (c->multi) return ctx_fail(c, CELLECTOR_EINVAL, "a multi-device ctx runs every shard on a stream of its own");
+    if (c->owns_stream) return ctx_fail(c, CELLECTOR_EINVAL, "this shard's stream belongs to its multi-device ctx");
     c->stream = (hipStream_t)s;
     return CELLECTOR_OK;
 }
@@ -260,6 +307,7 @@ cellector_status cellector_set_stream(cellector_ctx *c, void *s)
 cellector_status cellector_set_option(cellector_ctx *c, const char *key, int64_t v)
 {
     if (!c || !key) return CELLECTOR_EINVAL;
+    if (c->multi) return multi_set_option(c, key, v);
     if (!strcmp(key, "compute_expected")) c->compute_expected = v != 0;
     else if (!strcmp(key, "timing")) {
         c->timing = v < 0 ? 0 : (v > 2 ? 2 : (int)v);
@@ -271,6 +319,10 @@ cellector_status cellector_set_option(cellector_ctx *c, const char *key, int64_t
             }
     }
     else if (!strcmp(key, "keep_coo")) c->keep_coo = v != 0;
+    else if (!strcmp(key, "synth_continue_pct")) {
+        if (v < 0 || v > 90) return ctx_fail(c, CELLECTOR_EINVAL, "synth_continue_pct must be within 0..90");
+        c->synth_continue_pct = (int)v;
+    }
     else if (!strcmp(key, "overlap")) {
         if (v < 0 || v > 2) return ctx_fail(c, CELLECTOR_EINVAL, "overlap must be 0, 1 or 2");
         c->overlap = (int)v;
@@ -308,6 +360,8 @@ cellector_status cellector_set_option(cellector_ctx *c, const char *key, int64_t
 cellector_status cellector_set_shard(cellector_ctx *c, uint64_t b, uint64_t e)
 {
     if (!c) return CELLECTOR_EINVAL;
+    if (c->multi || comm_active(c->comm))
+        return ctx_fail(c, CELLECTOR_EINVAL, "a ctx with a communicator shards the cells itself (equal contiguous ranges by rank)");
     REQUIRE(c, c->state == cellector_ctx::ST_EMPTY, "set_shard must precede ingest");
     REQUIRE(c, b <= e, "empty or inverted shard range");
     c->cell_begin = b;
@@ -331,6 +385,11 @@ static cellector_status begin_ingest(cellector_ctx *c, uint64_t total_loci, uint
     REQUIRE(c, total_loci <= 0xffffffffull && total_cells <= 0xffffffffull, "dims exceed 32-bit indices");
     c->total_loci = total_loci;
     c->total_cells = total_cells;
+    if (comm_active(c->comm)) {  // rank r owns the r-th of n equal contiguous ranges (the NORM all-gather needs equal slots)
+        const uint64_t per = comm_cells_per_rank(total_cells, c->comm.n);
+        c->cell_begin = std::min(total_cells, (uint64_t)c->comm.rank * per);
+        c->cell_end = std::min(total_cells, c->cell_begin + per);
+    }
     if (c->cell_end > total_cells) c->cell_end = total_cells;
     if (c->cell_begin > c->cell_end) c->cell_begin = c->cell_end;
     c->nloc = c->cell_end - c->cell_begin;
@@ -350,6 +409,7 @@ cellector_status cellector_ingest_coo(cellector_ctx *c, uint64_t total_loci, uin
                                       const uint32_t *ref)
 {
     if (!c) return CELLECTOR_EINVAL;
+    if (c->multi) return multi_ingest_coo(c, total_loci, total_cells, nnz, locus0, cell0, alt, ref);
     REQUIRE(c, nnz == 0 || (locus0 && cell0 && alt && ref), "null COO array");
     CHK(begin_ingest(c, total_loci, total_cells));
     CHK(ingest_stage_host_coo(c, nnz, locus0, cell0, alt, ref));
@@ -370,8 +430,9 @@ static double lap_s(std::chrono::steady_clock::time_point *t)
 cellector_status cellector_ingest_mtx(cellector_ctx *c, const char *alt_path, const char *ref_path)
 {
     if (!c) return CELLECTOR_EINVAL;
+    if (c->multi) return multi_ingest_mtx(c, alt_path, ref_path);
     REQUIRE(c, alt_path && ref_path, "null path");
-    const bool timing = getenv("CELLECTOR_TIMING") != nullptr;
+    const bool timing = getenv("CELLECTOR_TIMING") != nullptr && c->comm.rank == 0;
     auto t = std::chrono::steady_clock::now();
     MtxInput *in = nullptr;
     uint64_t tl = 0, tc = 0;
@@ -392,6 +453,7 @@ cellector_status cellector_ingest_synthetic(cellector_ctx *c, uint64_t total_loc
                                             double doublet_fraction)
 {
     if (!c) return CELLECTOR_EINVAL;
+    if (c->multi) return multi_ingest_synthetic(c, total_loci, total_cells, density, seed, minority_fraction, doublet_fraction);
     CHK(begin_ingest(c, total_loci, total_cells));
     CHK(synth_generate(c, density, seed, minority_fraction, doublet_fraction));
     CHK(ingest_pass1(c));
@@ -402,6 +464,7 @@ cellector_status cellector_ingest_synthetic(cellector_ctx *c, uint64_t total_loc
 cellector_status cellector_write_staged_mtx(cellector_ctx *c, const char *alt_path, const char *ref_path)
 {
     if (!c) return CELLECTOR_EINVAL;
+    if (c->multi) return ctx_fail(c, CELLECTOR_EINVAL, "write_staged_mtx works on a single-device ctx (the staged entries of a multi-device ctx are sharded)");
     REQUIRE(c, alt_path && ref_path, "null path");
     REQUIRE(c, c->state != cellector_ctx::ST_EMPTY, "write_staged_mtx without a staged matrix");
     SETDEV(c);
@@ -411,10 +474,15 @@ cellector_status cellector_write_staged_mtx(cellector_ctx *c, const char *alt_pa
 cellector_status cellector_ingest_finish(cellector_ctx *c, uint64_t min_alt, uint64_t min_ref)
 {
     if (!c) return CELLECTOR_EINVAL;
+    if (c->multi) return multi_ingest_finish(c, min_alt, min_ref);
     REQUIRE(c, c->state == cellector_ctx::ST_STAGED, "ingest_finish without a staged matrix");
     SETDEV(c);
-    const bool timing = getenv("CELLECTOR_TIMING") != nullptr;
+    const bool timing = getenv("CELLECTOR_TIMING") != nullptr && c->comm.rank == 0;
     auto t = std::chrono::steady_clock::now();
+    if (comm_active(c->comm)) {  // exchange point 1: global pass-1 counts and allele totals (every shard applies the same locus filter)
+        CHK((cellector_status)comm_allreduce_sum(c, c->x_pass1, (uint64_t)P1_PLANES * c->total_loci));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
     CHK(ingest_build(c, min_alt, min_ref));
     if (timing) fprintf(stderr, "[timing]   CSC / CSR build         %8.3f s\n", lap_s(&t));
     const uint64_t L = c->L, n = c->nloc;
@@ -430,7 +498,9 @@ cellector_status cellector_ingest_finish(cellector_ctx *c, uint64_t min_alt, uin
     HIPCHK(c, hipMemsetAsync(c->ll, 0, (n ? n : 1) * 8, c->stream));
     HIPCHK(c, hipMemsetAsync(c->ell, 0, (n ? n : 1) * 8, c->stream));
     HIPCHK(c, hipMemsetAsync(c->nloci, 0, (n ? n : 1) * 8, c->stream));
-    const uint64_t need_norm = c->total_cells, need_locus = (uint64_t)LB_PLANES * L + LC_COUNTERS;
+    // (with a communicator every rank owns an equal slot of NORM: the in-place all-gather's layout)
+    const uint64_t need_norm = comm_active(c->comm) ? comm_cells_per_rank(c->total_cells, c->comm.n) * (uint64_t)c->comm.n : c->total_cells;
+    const uint64_t need_locus = (uint64_t)LB_PLANES * L + LC_COUNTERS;
     if (c->x_norm) REQUIRE(c, c->n_norm >= need_norm, "bound NORM exchange buffer too small");
     else { CHK(dev_alloc(c, &c->x_norm, need_norm)); c->own_norm = true; }
     if (c->x_locus) REQUIRE(c, c->n_locus >= need_locus, "bound LOCUS exchange buffer too small");
@@ -471,6 +541,7 @@ cellector_status cellector_load_coo(cellector_ctx *c, uint64_t tl, uint64_t tc, 
 cellector_status cellector_dims(const cellector_ctx *c, cellector_dims_t *o)
 {
     if (!c || !o) return CELLECTOR_EINVAL;
+    if (c->multi) return multi_dims(c, o);
     o->total_cells = c->total_cells; o->total_loci = c->total_loci; o->loci_used = c->L;
     o->cell_begin = c->cell_begin; o->cell_end = c->cell_end; o->nnz_used = c->nnz;
     return CELLECTOR_OK;
@@ -485,10 +556,21 @@ static cellector_status d2h(const cellector_ctx *c, void *dst, const void *src, 
     return CELLECTOR_OK;
 }
 #define READY(c) REQUIRE(c, (c) && (c)->state == cellector_ctx::ST_READY, "no matrix loaded")
+// per-locus state is replicated on every shard: shard 0 of a multi-device ctx answers
+#define SHARD0(c, call)                                                      \
+    do {                                                                     \
+        if ((c)->multi) {                                                    \
+            const cellector_ctx *s0__ = multi_shard0(c);                     \
+            const cellector_status st__ = (call);                            \
+            if (st__ != CELLECTOR_OK) (c)->err = s0__->err;                  \
+            return st__;                                                     \
+        }                                                                    \
+    } while (0)
 
 cellector_status cellector_locus_ids(const cellector_ctx *c, uint64_t *out)
 {
     if (!c) return CELLECTOR_EINVAL;
+    SHARD0(c, cellector_locus_ids(s0__, out));
     READY(c);
     return d2h(c, out, c->locus_ids, c->L * 8);
 }
@@ -496,6 +578,7 @@ cellector_status cellector_locus_ids(const cellector_ctx *c, uint64_t *out)
 cellector_status cellector_locus_counts(const cellector_ctx *c, double *out)
 {
     if (!c) return CELLECTOR_EINVAL;
+    SHARD0(c, cellector_locus_counts(s0__, out));
     READY(c);
     std::vector<double> a(c->L), r(c->L);
     CHK(d2h(c, a.data(), c->s_alt, c->L * 8));
@@ -507,6 +590,7 @@ cellector_status cellector_locus_counts(const cellector_ctx *c, double *out)
 cellector_status cellector_entries_per_cell(const cellector_ctx *c, uint32_t *out)
 {
     if (!c) return CELLECTOR_EINVAL;
+    if (c->multi) return multi_entries_per_cell(c, out);
     READY(c);
     std::vector<uint64_t> p(c->nloc + 1);
     CHK(d2h(c, p.data(), c->csr_ptr, (c->nloc + 1) * 8));
@@ -518,6 +602,7 @@ cellector_status cellector_csr_rows(const cellector_ctx *c, uint64_t rb, uint64_
                                     uint64_t *entries, uint64_t capacity)
 {
     if (!c) return CELLECTOR_EINVAL;
+    if (c->multi) return multi_csr_rows(c, rb, re, row_ptr, entries, capacity);
     READY(c);
     REQUIRE(c, rb <= re && re <= c->nloc && row_ptr, "bad row range");
     CHK(d2h(c, row_ptr, c->csr_ptr + rb, (re - rb + 1) * 8));
@@ -534,6 +619,7 @@ cellector_status cellector_csr_rows(const cellector_ctx *c, uint64_t rb, uint64_
 cellector_status cellector_exchange_buffer(cellector_ctx *c, cellector_xchg which, void **dev_ptr, uint64_t *n)
 {
     if (!c) return CELLECTOR_EINVAL;
+    if (c->multi) return ctx_fail(c, CELLECTOR_EINVAL, "the exchange buffers of a multi-device ctx are internal");
     double *p = nullptr;
     uint64_t cnt = 0;
     switch (which) {
@@ -553,6 +639,7 @@ cellector_status cellector_exchange_buffer(cellector_ctx *c, cellector_xchg whic
 cellector_status cellector_bind_exchange_buffer(cellector_ctx *c, cellector_xchg which, void *dev_ptr, uint64_t n)
 {
     if (!c || !dev_ptr) return CELLECTOR_EINVAL;
+    if (c->multi || comm_active(c->comm)) return ctx_fail(c, CELLECTOR_EINVAL, "a ctx with a communicator owns its exchange buffers");
     double *p = (double *)dev_ptr;
     c->tables_prebuilt = false;  // (tables built ahead read the old buffers)
     switch (which) {
@@ -587,13 +674,14 @@ cellector_status cellector_bind_exchange_buffer(cellector_ctx *c, cellector_xchg
 cellector_status cellector_em_begin(cellector_ctx *c)
 {
     if (!c) return CELLECTOR_EINVAL;
+    if (c->multi) return ctx_fail(c, CELLECTOR_EINVAL, "a multi-device ctx runs whole iterations: cellector_em_iteration");
     READY(c);
     REQUIRE(c, c->em_phase == 0, "em_begin: previous iteration not finished");
     SETDEV(c);
     // engine 2 forms alpha/beta inside its first kernel (k_build_tables); an empty shard has no cell pass at all
     if (c->engine != 2 || c->prebuilt_expected != c->compute_expected) c->tables_prebuilt = false;
     if (c->engine != 2 || c->nloc == 0) CHK(launch_alpha_beta(c));
-    if (c->nloc != c->total_cells && c->norm_zero)  // other shards' slices must be zero before a SUM exchange
+    if (c->nloc != c->total_cells && c->norm_zero && !comm_active(c->comm))  // other shards' slices must be zero before a SUM exchange
         HIPCHK(c, hipMemsetAsync(c->x_norm, 0, c->total_cells * 8, c->stream));
     cellector_status st = c->engine == 2 ? tiled_cell_pass(c, c->ab, c->x_norm + c->cell_begin, true)
                                          : launch_cell_ll(c, c->ab, c->x_norm + c->cell_begin);
@@ -606,11 +694,14 @@ cellector_status cellector_em_begin(cellector_ctx *c)
 cellector_status cellector_em_threshold(cellector_ctx *c, double iqr_multiple)
 {
     if (!c) return CELLECTOR_EINVAL;
+    if (c->multi) return ctx_fail(c, CELLECTOR_EINVAL, "a multi-device ctx runs whole iterations: cellector_em_iteration");
     READY(c);
     REQUIRE(c, c->em_phase == 1, "em_threshold without em_begin");
     SETDEV(c);
     const uint64_t n = c->total_cells;
     REQUIRE(c, n > 0, "no cells");
+    // exchange point 2 (a ctx with a communicator does it itself): every shard's slice of the normalised LLs
+    if (comm_active(c->comm)) CHK((cellector_status)comm_allgather_slices(c, c->x_norm, comm_cells_per_rank(n, c->comm.n)));
     // exact median / R-8 quartiles / threshold, all on the device (no host round trip in this phase)
     CHK(select_threshold(c, c->x_norm, n, iqr_multiple));
     // (the counters k_flag adds to were reset by this iteration's k_alpha_beta)
@@ -624,9 +715,12 @@ cellector_status cellector_em_threshold(cellector_ctx *c, double iqr_multiple)
 cellector_status cellector_em_finish(cellector_ctx *c, cellector_iter_summary *out)
 {
     if (!c) return CELLECTOR_EINVAL;
+    if (c->multi) return ctx_fail(c, CELLECTOR_EINVAL, "a multi-device ctx runs whole iterations: cellector_em_iteration");
     READY(c);
     REQUIRE(c, c->em_phase == 2, "em_finish without em_threshold");
     SETDEV(c);
+    // exchange point 3: per-locus minority tallies, contribution sums and the change counters
+    if (comm_active(c->comm)) CHK((cellector_status)comm_allreduce_sum(c, c->x_locus, (uint64_t)LB_PLANES * c->L + LC_COUNTERS));
     CHK(launch_locus_filter(c));
     CHK(launch_iter_summary(c));
     // the next iteration's first kernel is queued behind the summary: it runs while the host waits for the summary, wakes
@@ -688,6 +782,7 @@ cellector_status cellector_em_finish(cellector_ctx *c, cellector_iter_summary *o
 
 cellector_status cellector_em_iteration(cellector_ctx *c, double iqr_multiple, cellector_iter_summary *out)
 {
+    if (c && c->multi) return multi_em_iteration(c, iqr_multiple, out);
     CHK(cellector_em_begin(c));
     CHK(cellector_em_threshold(c, iqr_multiple));
     return cellector_em_finish(c, out);
@@ -696,6 +791,7 @@ cellector_status cellector_em_iteration(cellector_ctx *c, double iqr_multiple, c
 cellector_status cellector_iter_cell_outputs(const cellector_ctx *c, double *ll, double *ell, double *nl, double *norm)
 {
     if (!c) return CELLECTOR_EINVAL;
+    if (c->multi) return multi_iter_cell_outputs(c, ll, ell, nl, norm);
     READY(c);
     const size_t b = c->nloc * 8;
     if (ll) CHK(d2h(c, ll, c->ll, b));
@@ -710,6 +806,7 @@ cellector_status cellector_iter_locus_outputs(const cellector_ctx *c, double *cm
                                               uint64_t *rmaj)
 {
     if (!c) return CELLECTOR_EINVAL;
+    SHARD0(c, cellector_iter_locus_outputs(s0__, cmin, cmaj, nmin, nmaj, amin, rmin, amaj, rmaj));
     READY(c);
     REQUIRE(c, c->have_iter && c->em_phase == 0, "no finished iteration");
     const uint64_t L = c->L;
@@ -738,6 +835,7 @@ cellector_status cellector_iter_locus_outputs(const cellector_ctx *c, double *cm
 cellector_status cellector_loci_mask(const cellector_ctx *c, uint8_t *out)
 {
     if (!c) return CELLECTOR_EINVAL;
+    SHARD0(c, cellector_loci_mask(s0__, out));
     READY(c);
     return d2h(c, out, c->mask, c->L);
 }
@@ -745,6 +843,7 @@ cellector_status cellector_loci_mask(const cellector_ctx *c, uint8_t *out)
 cellector_status cellector_excluded(const cellector_ctx *c, uint8_t *out)
 {
     if (!c) return CELLECTOR_EINVAL;
+    if (c->multi) return multi_excluded(c, out);
     READY(c);
     return d2h(c, out, c->flags, c->nloc);
 }
@@ -752,6 +851,7 @@ cellector_status cellector_excluded(const cellector_ctx *c, uint8_t *out)
 cellector_status cellector_alpha_betas(const cellector_ctx *c, double *alpha, double *beta)
 {
     if (!c) return CELLECTOR_EINVAL;
+    SHARD0(c, cellector_alpha_betas(s0__, alpha, beta));
     READY(c);
     const uint64_t L = c->L;
     std::vector<double> buf(LB_PLANES * L), sa(L), sr(L);
@@ -769,6 +869,7 @@ cellector_status cellector_cell_log_likelihoods(cellector_ctx *c, const double *
                                                 const uint8_t *mask, double *ll, double *ell, double *nl)
 {
     if (!c) return CELLECTOR_EINVAL;
+    if (c->multi) return multi_cell_log_likelihoods(c, alpha, beta, mask, ll, ell, nl);
     READY(c);
     REQUIRE(c, alpha && beta, "null alpha/beta");
     REQUIRE(c, c->em_phase == 0, "iteration in flight");
@@ -792,6 +893,7 @@ cellector_status cellector_posteriors(cellector_ctx *c, double *posterior, doubl
                                       double *ll_min)
 {
     if (!c) return CELLECTOR_EINVAL;
+    if (c->multi) return multi_posteriors(c, posterior, doublet, ll_maj, ll_min);
     READY(c);
     REQUIRE(c, c->em_phase == 0, "iteration in flight");
     SETDEV(c);
@@ -816,6 +918,7 @@ cellector_status cellector_final_allele_tallies(cellector_ctx *c, uint64_t *alt_
                                                 uint64_t *alt_maj, uint64_t *ref_maj)
 {
     if (!c) return CELLECTOR_EINVAL;
+    if (c->multi) return multi_final_allele_tallies(c, alt_min, ref_min, alt_maj, ref_maj);
     READY(c);
     REQUIRE(c, c->keep_coo, "final tallies need the staged COO (option keep_coo=1)");
     SETDEV(c);
@@ -837,6 +940,7 @@ cellector_status cellector_final_allele_tallies(cellector_ctx *c, uint64_t *alt_
 cellector_status cellector_engine_info(const cellector_ctx *c, cellector_engine_info_t *o)
 {
     if (!c || !o) return CELLECTOR_EINVAL;
+    if (c->multi) return multi_engine_info(c, o);
     memset(o, 0, sizeof *o);
     o->engine = (uint64_t)c->engine;
     if (c->tiled_ready) {
@@ -845,6 +949,7 @@ cellector_status cellector_engine_info(const cellector_ctx *c, cellector_engine_
         o->cell_blocks = c->t_nb; o->locus_chunks = c->t_nj; o->chunk_groups = c->t_groups;
         const uint64_t elems = c->t_elems + (uint64_t)c->t_nb * c->t_nj * 128;  // slices + slice headers (u16 units)
         o->tile_bytes = elems * 2;
+        o->tile_lookups = c->t_elems - (uint64_t)c->t_nb * c->t_nj * T_ROWS_PER_TILE;  // a row = its cell id + K entries
     }
     return CELLECTOR_OK;
 }
@@ -853,6 +958,7 @@ cellector_status cellector_engine_info(const cellector_ctx *c, cellector_engine_
 cellector_status cellector_kernel_time(cellector_ctx *c, cellector_kernel_id which, double *total_ms, uint64_t *launches)
 {
     if (!c || which < 0 || which >= CELLECTOR_K_COUNT) return CELLECTOR_EINVAL;
+    if (c->multi) return cellector_kernel_time(multi_shard0(c), which, total_ms, launches);
     (void)hipSetDevice(c->device);
     timer_collect(c);
     if (total_ms) *total_ms = c->timers[which].total_ms;
@@ -863,6 +969,7 @@ cellector_status cellector_kernel_time(cellector_ctx *c, cellector_kernel_id whi
 cellector_status cellector_reset_timing(cellector_ctx *c)
 {
     if (!c) return CELLECTOR_EINVAL;
+    if (c->multi) return multi_reset_timing(c);
     (void)hipSetDevice(c->device);
     timer_collect(c);
     for (int k = 0; k < CELLECTOR_K_COUNT; k++) { c->timers[k].total_ms = 0.0; c->timers[k].launches = 0; }

@@ -1,0 +1,53 @@
+// Exchange layer of a sharded run (not part of the public ABI).  The scoring loop has three exchange points
+// (include/cellector_ffi.h): PASS1 once at load (sum), NORM per iteration (all-gather of equal cell slices), LOCUS per
+// iteration (sum).  Two transports behind one interface:
+//   * RCCL over xGMI (one communicator rank per shard; ncclCommInitAll inside one process, ncclCommInitRank across
+//     processes).  librccl is opened lazily: a single-GPU run never loads it.
+//   * a same-process group for logical shards that SHARE a device (RCCL refuses duplicate devices): host barrier +
+//     device-side sums in rank order.  Tests and one-GPU rehearsals of the sharded path use it.
+#pragma once
+#include <condition_variable>
+#include <cstdint>
+#include <mutex>
+#include <vector>
+
+struct cellector_ctx;
+
+#define CELLECTOR_MAX_SHARDS 16
+
+// shards of one process that exchange through device memory they can all reach
+struct LocalGroup {
+    int n = 0;
+    std::mutex mu;
+    std::condition_variable cv;
+    int arrived = 0;
+    uint64_t generation = 0;
+    const double *bufs[CELLECTOR_MAX_SHARDS] = {};
+    bool failed = false;  // a shard gave up (error path): the others must not wait for it
+    bool barrier();       // false: the group has failed
+    void fail();
+};
+
+struct Comm {
+    int n = 1, rank = 0;
+    void *nccl = nullptr;         // ncclComm_t of this shard (RCCL transport)
+    LocalGroup *local = nullptr;  // same-process transport (shared by the group's shards; owned by the root ctx)
+    double *tmp = nullptr;        // local transport: scratch for the sums, sized on first use
+    uint64_t tmp_n = 0;
+};
+
+// a communicator is attached (n = 1 with one: the single-rank self-test of the RCCL plumbing)
+static inline bool comm_active(const Comm &m) { return m.n > 1 || m.nccl != nullptr; }
+// cells per rank of the canonical contiguous split (the NORM all-gather needs equal slots)
+static inline uint64_t comm_cells_per_rank(uint64_t total_cells, int n) { return (total_cells + (uint64_t)n - 1) / (uint64_t)n; }
+
+int comm_status_ok();  // CELLECTOR_OK as int (keeps this header free of the public one)
+// sum over all shards, in place, on the ctx's stream; every shard ends with the same bits
+int comm_allreduce_sum(cellector_ctx *c, double *buf, uint64_t count);
+// every shard contributes buf[rank*per .. +per) and receives the others' slices (buf holds n*per doubles)
+int comm_allgather_slices(cellector_ctx *c, double *buf, uint64_t per);
+// RCCL: unique id for ncclCommInitRank, communicator set-up / tear-down
+int comm_rccl_unique_id(void *out128, const char **err);
+int comm_rccl_init_rank(cellector_ctx *c, const void *id128, int n, int rank);
+int comm_rccl_init_all(cellector_ctx **shards, int n, const int *devices);
+void comm_destroy(cellector_ctx *c);

@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "../../include/cellector_ffi.h"
+#include "comm.h"
 
 // ---- packed matrix entry -------------------------------------------------------------------
 // CSR (by cell):  bits 0..31 compact locus index, 32..47 alt count, 48..63 ref count
@@ -31,6 +32,7 @@ enum { P1_CELLS_REF = 0, P1_CELLS_ALT = 1, P1_SUM_REF = 2, P1_SUM_ALT = 3, P1_EN
 // d_counters slots (u32)
 enum { DC_N_FILTERED = 0, DC_N_MIN = 4 /* members of this shard's new exclusion set (k_flag) */ };
 
+#define T_ROWS_PER_TILE 1024  // rows (cells) of a tile of the tiled layout (= T_BC in kernels_tiled.hip)
 #define CELLECTOR_TILE_WORK_STRIDE 64  // column counters per table set of the persistent tile kernel (= T_GROUPS_MAX)
 
 #define LF_TABLE_N 171  // ln(FCACHE[0..170]) — statrs ln_factorial cache, SURVEY Appendix B.2
@@ -41,7 +43,15 @@ struct KernelTimer {
     uint64_t launches = 0;
 };
 
+struct MultiCtx;  // multi.cpp: the shards and worker threads of a ctx made by cellector_create_multi
+
 struct cellector_ctx {
+    // a ROOT ctx (cellector_create_multi with more than one shard) owns no device state of its own: every entry point
+    // fans out to its shards (multi.cpp) and returns arrays in global cell order
+    MultiCtx *multi = nullptr;
+    // the exchange transport of a shard that is part of a sharded run (n = 1: single shard, nothing is exchanged)
+    Comm comm;
+    bool owns_stream = false;  // the stream was created by the library (a shard of a root ctx)
     int device = 0;
     hipStream_t stream = nullptr;
     // side stream for the small overflow kernels that run next to the tile kernel (fork/join with events)
@@ -57,6 +67,7 @@ struct cellector_ctx {
     bool norm_zero = true;  // option: clear the other shards' slices of NORM before the cell pass (needed by a sum exchange)
     int timing = 0;  // 0 off, 1 every timed region, 2 only the dominant kernel of the engine
     bool keep_coo = true;
+    int synth_continue_pct = 30;  // option synth_continue_pct: the synthetic generator's n = 1 + Geometric(1 - pct/100)
 
     // shard
     uint64_t cell_begin = 0, cell_end = UINT64_MAX;

@@ -4,7 +4,9 @@
 //
 //   mix(z)        = splitmix64 finaliser
 //   present(l,c)  = (mix(S_lc ^ (l<<32 | c)) >> 40) < round(density * 2^24)             c = GLOBAL cell id
-//   n(l,c)        = 1 + #{k>=1 : low32(h2) < floor(0.3^k * 2^32)},  h2 = mix(h1 + GOLD)   (1 + Geometric(0.7))
+//   n(l,c)        = 1 + #{k>=1 : low32(h2) < T_k},  h2 = mix(h1 + GOLD)   (1 + Geometric(1 - q)); default q = 0.3:
+//                   T_k = floor(0.3^k * 2^32) (the table below); option "synth_continue_pct" = p != 30 (deeper coverage,
+//                   benchmarks of the count distribution): T_0 = 2^32, T_k = floor(T_{k-1} * p / 100), k < 64
 //   class(c)      = minority if (mix(S_min ^ c) >> 40) < round(minority_fraction * 2^24)
 //                   doublet  if (mix(S_dbl ^ c) >> 40) < round(doublet_fraction * 2^24)  (takes precedence)
 //   genotype(l,S) = v = mix(S ^ l) >> 48 : v < 32768 -> 0/0, v < 52428 -> 0/1, else 1/1  (p = .5/.3/.2)
@@ -18,11 +20,14 @@
 #define SY_CHUNK (SY_BLOCK * SY_CELLS_PER_THREAD)  // 16384 cells per tile
 #define GOLD 0x9E3779B97F4A7C15ull
 
+#define SY_GEOM_MAX 64
 struct SynthParams {
     uint64_t s_lc, s_min, s_dbl, s_gmaj, s_gmin;
     uint32_t thr_density, thr_min, thr_dbl;
     uint32_t nchunks;
     uint64_t cell_begin, nloc;
+    uint32_t n_geom;       // thresholds in geom[1..n_geom-1]
+    uint32_t geom[SY_GEOM_MAX];
 };
 
 __device__ __forceinline__ uint64_t mix64(uint64_t z)
@@ -33,7 +38,7 @@ __device__ __forceinline__ uint64_t mix64(uint64_t z)
     return z;
 }
 
-__constant__ uint32_t SY_GEOM[19] = {0u, 1288490188u, 386547056u, 115964116u, 34789235u, 10436770u, 3131031u,
+static const uint32_t SY_GEOM[19] = {0u, 1288490188u, 386547056u, 115964116u, 34789235u, 10436770u, 3131031u,
                                      939309u, 281792u, 84537u, 25361u, 7608u, 2282u, 684u, 205u, 61u, 18u, 5u, 1u};
 
 __device__ __forceinline__ uint32_t genotype_af16(uint64_t s, uint32_t l)
@@ -103,8 +108,8 @@ __global__ __launch_bounds__(SY_BLOCK) void k_synth_fill(SynthParams p, uint64_t
         const uint64_t h2 = mix64(h1 + GOLD);
         const uint32_t u = (uint32_t)h2;
         uint32_t n = 1;
-        for (int k = 1; k < 19; k++) {
-            if (u < SY_GEOM[k]) n++; else break;
+        for (uint32_t k = 1; k < p.n_geom; k++) {
+            if (u < p.geom[k]) n++; else break;
         }
         uint32_t af = ((uint32_t)(mix64(p.s_min ^ cg) >> 40) < p.thr_min) ? af_min : af_maj;
         if ((uint32_t)(mix64(p.s_dbl ^ cg) >> 40) < p.thr_dbl) af = (af_maj + af_min) >> 1;
@@ -145,6 +150,18 @@ cellector_status synth_generate(cellector_ctx *c, double density, uint64_t seed,
     p.thr_min = (uint32_t)(minority_fraction * 16777216.0 + 0.5);
     p.thr_dbl = (uint32_t)(doublet_fraction * 16777216.0 + 0.5);
     p.cell_begin = c->cell_begin; p.nloc = c->nloc;
+    memset(p.geom, 0, sizeof p.geom);
+    if (c->synth_continue_pct == 30) {
+        p.n_geom = 19;
+        for (int k = 0; k < 19; k++) p.geom[k] = SY_GEOM[k];
+    } else {
+        p.n_geom = SY_GEOM_MAX;
+        uint64_t t = 1ull << 32;
+        for (int k = 1; k < SY_GEOM_MAX; k++) {
+            t = t * (uint64_t)c->synth_continue_pct / 100u;
+            p.geom[k] = (uint32_t)t;
+        }
+    }
     p.nchunks = (uint32_t)((c->nloc + SY_CHUNK - 1) / SY_CHUNK);
     const uint64_t ntiles = c->total_loci * p.nchunks;
     uint64_t *tiles = nullptr;

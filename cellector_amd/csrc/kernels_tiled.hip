@@ -37,6 +37,7 @@
 #define T_BLU (T_BL - 1)  // loci per chunk
 #define T_BC 1024       // cells per block == threads per workgroup
 #define T_THREADS 1024
+static_assert(T_BC == T_ROWS_PER_TILE, "cellector_engine_info derives the lookup count from this");
 #define T_SB_MAX 4      // cell blocks per workgroup sharing one staged table (2 or 4: chosen per launch)
 #define T_GROUPS_MAX 64 // upper bound of the chunk groups of a launch
 #define T_GROUPS 8      // chunk groups (== XCDs: the workgroups of a group run on one XCD and share its L2)

@@ -5,6 +5,7 @@ library is missing or no GPU is present, construction fails loudly.
 """
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
@@ -20,6 +21,10 @@ _vp, _u64, _d, _cp, _i = C.c_void_p, C.c_uint64, C.c_double, C.c_char_p, C.c_int
 SIGNATURES = {
     "cellector_create": (_i, [C.POINTER(_vp), _i]),
     "cellector_destroy": (None, [_vp]),
+    "cellector_device_count": (_i, [C.POINTER(_i)]),
+    "cellector_create_multi": (_i, [C.POINTER(_vp), C.POINTER(_i), _i]),
+    "cellector_comm_unique_id": (_i, [_vp]),
+    "cellector_comm_init_rank": (_i, [_vp, _vp, _i, _i]),
     "cellector_last_error": (_cp, [_vp]),
     "cellector_version": (_cp, []),
     "cellector_set_stream": (_i, [_vp, _vp]),
@@ -64,7 +69,7 @@ class Dims(C.Structure):
 
 class EngineInfo(C.Structure):
     _fields_ = [("engine", _u64), ("nnz_regular", _u64), ("nnz_overflow", _u64), ("tile_bytes", _u64),
-                ("cell_blocks", _u64), ("locus_chunks", _u64), ("chunk_groups", _u64), ("reserved", _u64)]
+                ("cell_blocks", _u64), ("locus_chunks", _u64), ("chunk_groups", _u64), ("tile_lookups", _u64)]
 
 
 class IterSummary(C.Structure):
@@ -86,6 +91,14 @@ def load_library(path=LIB_PATH):
     global _lib
     if _lib is not None and path == LIB_PATH:
         return _lib
+    # PyTorch-ROCm ships its own copy of the HIP runtime.  A process that uses both this library and torch.cuda must load
+    # torch's copy FIRST (this library then binds to it by soname); the other order leaves two runtimes in the process and
+    # torch.cuda fails to initialise ("No HIP GPUs are available").  CELLECTOR_NO_TORCH=1 skips this (torch-free hosts).
+    if "torch" not in sys.modules and not os.environ.get("CELLECTOR_NO_TORCH"):
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     if not os.path.exists(path):
         raise FileNotFoundError(f"{path} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
                                 "(cellector_amd has no CPU fallback)")
@@ -105,10 +118,16 @@ def _p(a):
 class Cellector:
     """One shard of a (locus x cell) matrix on one GPU; mirrors the reference's main() flow."""
 
-    def __init__(self, device=0, stream=None):
+    def __init__(self, device=0, stream=None, devices=None):
+        """devices=[d0, d1, ...]: ONE ctx over several GPUs (cellector_create_multi; a device listed twice = logical
+        shards on that GPU); every method then works on the whole matrix, arrays in global cell order."""
         self._lib = load_library()
         h = C.c_void_p()
-        st = self._lib.cellector_create(C.byref(h), int(device))
+        if devices is not None and len(devices) > 1:
+            ids = (C.c_int * len(devices))(*[int(d) for d in devices])
+            st = self._lib.cellector_create_multi(C.byref(h), ids, len(devices))
+        else:
+            st = self._lib.cellector_create(C.byref(h), int(devices[0] if devices else device))
         if st != 0:
             raise CellectorError(st, "cellector_create failed (no MI355X visible? the HIP path is mandatory)")
         self.h = h
@@ -143,6 +162,11 @@ class Cellector:
     def set_stream(self, stream):
         """hipStream_t as an integer (e.g. torch.cuda.current_stream().cuda_stream); 0 / None = the null stream"""
         self._ck(self._lib.cellector_set_stream(self.h, C.c_void_p(stream or None)))
+
+    def comm_init_rank(self, unique_id, n_ranks, rank):
+        """attach an RCCL communicator (one process per GPU); unique_id = the 128 bytes of comm_unique_id() on rank 0"""
+        buf = (C.c_char * 128).from_buffer_copy(bytes(unique_id))
+        self._ck(self._lib.cellector_comm_init_rank(self.h, buf, int(n_ranks), int(rank)))
 
     def set_shard(self, cell_begin, cell_end):
         self._ck(self._lib.cellector_set_shard(self.h, int(cell_begin), int(cell_end)))
@@ -310,6 +334,21 @@ class Cellector:
 
     def reset_timing(self):
         self._ck(self._lib.cellector_reset_timing(self.h))
+
+
+def device_count():
+    n = C.c_int(0)
+    load_library().cellector_device_count(C.byref(n))
+    return n.value
+
+
+def comm_unique_id():
+    """128 opaque bytes (ncclUniqueId) for Cellector.comm_init_rank; made on rank 0, broadcast by the host"""
+    buf = (C.c_char * 128)()
+    st = load_library().cellector_comm_unique_id(buf)
+    if st != 0:
+        raise CellectorError(st, "cellector_comm_unique_id failed (RCCL not loadable?)")
+    return bytes(buf)
 
 
 def assignments(posterior, doublet_posterior, entries_per_cell, excluded, posterior_threshold=0.999,

@@ -34,6 +34,17 @@ def _seeds(seed):
         return [mix64(base + np.uint64(k)) for k in range(1, 6)]
 
 
+def geom_table(continue_pct=30):
+    """thresholds T_k of n = 1 + #{k >= 1 : low32(h2) < T_k} (see csrc/kernels_synth.hip)"""
+    if continue_pct == 30:
+        return GEOM
+    t, out = 1 << 32, [0]
+    for _ in range(1, 64):
+        t = t * int(continue_pct) // 100
+        out.append(t)
+    return np.array(out, dtype=np.uint64)
+
+
 def _thr24(x):
     return np.uint64(int(x * 16777216.0 + 0.5))
 
@@ -54,7 +65,7 @@ def cell_classes(total_cells, seed=4, minority_fraction=0.05, doublet_fraction=0
 
 
 def generate_coo(total_loci, total_cells, density, seed=4, minority_fraction=0.05, doublet_fraction=0.0,
-                 cell_begin=0, cell_end=None):
+                 cell_begin=0, cell_end=None, continue_pct=30):
     """COO triplets sorted by (locus, cell), 0-based GLOBAL indices: locus, cell, alt, ref (uint32 each)."""
     cell_end = total_cells if cell_end is None else cell_end
     s_lc, s_min, s_dbl, s_gmaj, s_gmin = _seeds(seed)
@@ -64,6 +75,7 @@ def generate_coo(total_loci, total_cells, density, seed=4, minority_fraction=0.0
     loci = np.arange(total_loci, dtype=np.uint64)
     af_maj, af_min = genotype_af16(s_gmaj, loci), genotype_af16(s_gmin, loci)
     thr = _thr24(density)
+    geom = geom_table(continue_pct)
     out_l, out_c, out_a, out_r = [], [], [], []
     with np.errstate(over="ignore"):
         for l in range(total_loci):
@@ -76,8 +88,8 @@ def generate_coo(total_loci, total_cells, density, seed=4, minority_fraction=0.0
             u = h2 & np.uint64(0xFFFFFFFF)
             n = np.ones(sel.size, np.uint32)
             alive = np.ones(sel.size, bool)
-            for k in range(1, 19):
-                alive &= u < GEOM[k]
+            for k in range(1, len(geom)):
+                alive &= u < geom[k]
                 if not alive.any():
                     break
                 n += alive

@@ -133,7 +133,8 @@ struct Params {
     uint64_t min_alt = 4, min_ref = 4, min_alleles_posterior = 5, min_loci_used = 30;
     double posterior_threshold = 0.999, interquartile_range_multiple = 5.0;
     std::optional<double> expected_percent_minority;  // parsed, never used (quirk Q2)
-    int device = 0;                                    // extension: which GPU
+    int device = -1;                                   // extension: ONE GPU to run on
+    std::vector<int> devices;                          // extension: the GPUs to shard the cells over (default: automatic)
 };
 
 const char *USAGE =
@@ -153,7 +154,10 @@ const char *USAGE =
     "        --posterior_threshold <posterior_threshold>                    posterior threshold for assignment (default 0.999)\n"
     "    -r, --ref <ref>                                                    ref.mtx matrix from vartrix\n"
     "    -v, --vcf <vcf>                                                    vcf associated with alt.mtx and ref.mtx\n"
-    "        --device <n>                                                   GPU to run on (default 0; not in the reference)\n";
+    "        --device <n>                                                   run on this one GPU (not in the reference)\n"
+    "        --devices <a,b,...>                                            GPUs to shard the cells over, RCCL exchanges between them (not in\n"
+    "                                                                       the reference; default: all visible GPUs for inputs of several GB\n"
+    "                                                                       per GPU, else GPU 0; a GPU listed twice = two logical shards on it)\n";
 
 uint64_t parse_usize(const std::string &name, const std::string &s)
 {
@@ -177,7 +181,7 @@ Params load_params(int argc, char **argv)
                                                               {"-g", "ground_truth"}, {"-v", "vcf"}};
     static const char *known[] = {"output_directory", "ref", "alt", "barcodes", "min_alt", "min_ref", "ground_truth",
                                   "vcf", "posterior_threshold", "interquartile_range_multiple", "min_alleles_posterior",
-                                  "expected_percent_minority", "min_loci_for_assignment", "device"};
+                                  "expected_percent_minority", "min_loci_for_assignment", "device", "devices"};
     std::map<std::string, std::string> got;
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i], name, value;
@@ -218,6 +222,9 @@ Params load_params(int argc, char **argv)
     if (got.count("expected_percent_minority")) p.expected_percent_minority = parse_f64("expected_percent_minority", got["expected_percent_minority"]);
     if (got.count("min_loci_for_assignment")) p.min_loci_used = parse_usize("min_loci_for_assignment", got["min_loci_for_assignment"]);
     if (got.count("device")) p.device = (int)parse_usize("device", got["device"]);
+    if (got.count("devices"))
+        for (const std::string &t : split(got["devices"], ',')) p.devices.push_back((int)parse_usize("devices", t));
+    if (got.count("device") && got.count("devices")) die(1, "error: The argument '--device <n>' cannot be used with '--devices <a,b,...>'");
     return p;
 }
 
@@ -324,9 +331,26 @@ int main(int argc, char **argv)
         t_prev = now;
     };
     // load_cell_data (load_data.rs:134-181) on the device
+    // Which GPUs: --device n / --devices a,b,... as given; else all visible GPUs when the input is large enough to feed them
+    // (one GPU per 4 GB of alt.mtx text, i.e. >= 1.3e8 entries each: below that the per-iteration exchanges and the
+    // communicator set-up cost more than the extra GPUs save), else GPU 0.  cellector_pipeline.py:223-226 passes neither flag.
     Ctx g;
-    if (cellector_create(&g.c, params.device) != CELLECTOR_OK)
-        die(EXIT_PANIC, "cellector: no usable MI355X device " + std::to_string(params.device) + " (there is no CPU fallback)");
+    std::vector<int> devices = params.devices;
+    if (devices.empty() && params.device >= 0) devices.push_back(params.device);
+    if (devices.empty()) {
+        int visible = 0;
+        (void)cellector_device_count(&visible);
+        struct stat sb;
+        const uint64_t alt_bytes = stat(params.alt_mtx.c_str(), &sb) == 0 ? (uint64_t)sb.st_size : 0;
+        uint64_t want = alt_bytes / (4ull << 30);
+        if (params.alt_mtx.size() > 3 && params.alt_mtx.compare(params.alt_mtx.size() - 3, 3, ".gz") == 0) want *= 4;  // (text is ~4x the .gz)
+        if (const char *e = getenv("CELLECTOR_DEVICES_AUTO_MAX")) visible = std::min(visible, atoi(e));
+        const int n = (int)std::max<uint64_t>(1, std::min<uint64_t>(want, (uint64_t)std::min(visible, 16)));
+        for (int i = 0; i < n; i++) devices.push_back(i);
+    }
+    if (cellector_create_multi(&g.c, devices.data(), (int)devices.size()) != CELLECTOR_OK)
+        die(EXIT_PANIC, "cellector: no usable MI355X device (asked for " + std::to_string(devices.size()) + ", first: " +
+                            std::to_string(devices[0]) + "; there is no CPU fallback)");
     if (const char *e = getenv("CELLECTOR_ENGINE")) g.ck(cellector_set_option(g.c, "engine", atoi(e)), "engine");
     g.ck(cellector_set_option(g.c, "keep_coo", params.vcf ? 1 : 0), "option");
     lap("barcodes + device init");
@@ -553,7 +577,9 @@ int main(int argc, char **argv)
     // process' memory in one go.
     fflush(stdout);
     fflush(stderr);
-    if (getenv("CELLECTOR_TEARDOWN")) {  // (a profiler's exit handlers, leak checkers: the orderly way out)
+    // (a multi-device ctx always leaves the orderly way: its communicator and worker threads are torn down in order;
+    //  so does a run under a profiler or leak checker, CELLECTOR_TEARDOWN=1)
+    if (devices.size() > 1 || getenv("CELLECTOR_TEARDOWN")) {
         cellector_destroy(g.c);
         return 0;
     }

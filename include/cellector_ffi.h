@@ -13,10 +13,12 @@
  *  - plain pointers and sizes only; host output buffers are caller-allocated and caller-owned;
  *  - a ctx owns all device memory, is bound to one GPU, and is driven by one host thread at a time;
  *  - a ctx holds ONE SHARD of the matrix: the cells [cell_begin, cell_end) of the global cell
- *    range, all loci.  Per-locus state is replicated on every shard.  Multi-GPU = one process per
- *    GPU, one ctx each; the three exchange buffers below are all-reduced (f64 sum) by the host
- *    (torch.distributed/RCCL) at the marked points.  With a single shard nothing is exchanged and
- *    cellector_em_iteration() runs the three phases back to back;
+ *    range, all loci.  Per-locus state is replicated on every shard.  Multi-GPU: either ONE ctx over
+ *    several devices (cellector_create_multi) or one process per GPU with a communicator attached to
+ *    its ctx (cellector_comm_init_rank) — in both the library runs the three exchanges itself over
+ *    RCCL/xGMI; or, without a communicator, the host sums the three exchange buffers below at the
+ *    marked points (cellector_set_shard + bind_exchange_buffer: e.g. torch.distributed tensors).  With
+ *    a single shard nothing is exchanged and cellector_em_iteration() runs the phases back to back;
  *  - every kernel is launched on the ctx's stream (default: the null stream).
  */
 #ifndef CELLECTOR_FFI_H
@@ -44,6 +46,27 @@ typedef enum {
 /* ---- lifecycle ----------------------------------------------------------------------------- */
 cellector_status cellector_create(cellector_ctx **out, int device_id);
 void cellector_destroy(cellector_ctx *ctx);
+/* number of visible GPUs (0 without one; never fails the process) */
+cellector_status cellector_device_count(int *out);
+
+/* ---- multi-GPU (the reference is ONE binary, main.rs:25-50: the host sees one logical matrix) ---------------
+ * (1) One process, several GPUs.  The ctx owns one shard per listed device (rank r = the r-th of n equal contiguous
+ *     cell ranges; per-locus state replicated), one host thread and one stream per shard, and an RCCL communicator
+ *     over the devices (ncclCommInitAll).  EVERY entry point below works on it unchanged — ingest, cellector_em_iteration,
+ *     outputs, posteriors, final tallies — and returns arrays in GLOBAL cell order; the three exchanges (PASS1 at load,
+ *     NORM all-gather and LOCUS all-reduce per iteration) run inside the library over xGMI.  Not available on it:
+ *     cellector_set_stream / set_shard / bind_exchange_buffer / em_begin|threshold|finish (internal) and
+ *     cellector_write_staged_mtx.  n_devices == 1 gives a plain ctx.  A device listed more than once gives logical
+ *     shards on that GPU, exchanged by device-side sums instead of RCCL (which refuses duplicate devices): the same
+ *     sharded code path on a one-GPU box (tests, rehearsals).  At most 16 shards. */
+cellector_status cellector_create_multi(cellector_ctx **out, const int *device_ids, int n_devices);
+/* (2) One process per GPU (torch.distributed / MPI launchers).  Rank 0 makes an id, the host broadcasts its 128 bytes by
+ *     whatever means it has, every rank attaches a communicator to its own single-device ctx BEFORE the ingest.  The ctx
+ *     then owns rank r's cell range and performs the exchanges itself: cellector_ingest_finish all-reduces PASS1,
+ *     cellector_em_threshold first all-gathers NORM, cellector_em_finish first all-reduces LOCUS (so cellector_em_iteration
+ *     is the whole distributed iteration); per-cell outputs are this rank's cells.  CELLECTOR_ECOMM on RCCL failures. */
+cellector_status cellector_comm_unique_id(void *out_128_bytes);
+cellector_status cellector_comm_init_rank(cellector_ctx *ctx, const void *unique_id_128_bytes, int n_ranks, int rank);
 const char *cellector_last_error(const cellector_ctx *ctx); /* ctx-owned, valid until next call */
 const char *cellector_version(void);
 /* hipStream_t to launch on (e.g. torch.cuda.current_stream().cuda_stream); NULL = null stream. */
@@ -69,6 +92,8 @@ cellector_status cellector_set_stream(cellector_ctx *ctx, void *hip_stream);
  * a multiple of 8 up to 64 forces it — set before ingest; results may differ in the last bit),
  * "parse_window" (default 0: a text file of 1 GB or more is uploaded and tokenised in 256 MB windows, a smaller
  * one whole; a positive value forces windows of that many bytes — tests; lines of a windowed file may be 1 MB long),
+ * "synth_continue_pct" (default 30: cellector_ingest_synthetic draws an entry's total as 1 + Geometric(0.7), vartrix-like
+ * shallow coverage; a larger value gives deeper counts, e.g. 60 = 1 + Geometric(0.4) — benchmarks of the count distribution),
  * "norm_zero" (default 1: a shard clears the other shards' slices of CELLECTOR_XCHG_NORM before it writes
  * its own, so that a SUM all-reduce completes the array; 0 when the caller all-gathers the slices). */
 cellector_status cellector_set_option(cellector_ctx *ctx, const char *key, int64_t value);
@@ -207,7 +232,8 @@ typedef struct {
     uint64_t nnz_overflow;  /* the rest: evaluated individually                                           */
     uint64_t tile_bytes;    /* bytes of the tiled cell-pass layout                                        */
     uint64_t cell_blocks, locus_chunks, chunk_groups;
-    uint64_t reserved;
+    uint64_t tile_lookups;  /* table lookups one pass of the tile kernel performs: the regular entries plus the padding
+                               of the sliced-ELLPACK rows (each lookup = one or two 8-byte LDS reads)              */
 } cellector_engine_info_t;
 cellector_status cellector_engine_info(const cellector_ctx *ctx, cellector_engine_info_t *out);
 

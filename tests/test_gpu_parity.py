@@ -127,6 +127,23 @@ def test_synthetic_generator_matches_host_twin(mods):
             assert info.cell_blocks == 40 and info.locus_chunks == 1
 
 
+def test_deep_coverage_generator_matches_host_twin(mods):
+    """option synth_continue_pct (bench.py's *-deep workloads): totals 1 + Geometric(0.4) instead of 1 + Geometric(0.7);
+    the device generator and its numpy twin must still agree entry for entry, and the run must match the oracle (13 % of
+    the entries take the overflow paths here instead of 0.8 %)."""
+    L, N, d = 500, 3000, 0.05
+    lo, ce, al, re = mods["synth"].generate_coo(L, N, d, seed=13, minority_fraction=0.08, continue_pct=60)
+    assert (al + re).max() > 12 and ((al + re) > 4).mean() > 0.08
+    g = mods["Cellector"](0)
+    g.set_option("synth_continue_pct", 60)
+    g.load_synthetic(L, N, d, seed=13, minority_fraction=0.08)
+    o = mods["ob"].Oracle.from_coo(L, N, lo, ce, al, re)
+    _check_matrix(g, o)
+    _run_both(g, o)
+    _check_posteriors(mods, g, o)
+    g.close(); o.close()
+
+
 def test_cfg1_full_loop_and_posteriors(mods):
     g, o, _ = _case(mods, 2000, 1000, 0.10)
     _check_matrix(g, o)

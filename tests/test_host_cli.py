@@ -203,6 +203,42 @@ def test_full_run_matches_oracle(host_bin, oracle_lib, tmp_path, gz):
 
 
 @pytest.mark.gpu
+def test_devices_flag_shards_the_run(host_bin, tmp_path):
+    """`--devices 0,0,0`: the cells sharded over three logical shards of GPU 0, exchanges inside the library — the files
+    must be those of the single-device run: byte-identical where only per-cell results and integer tallies go in
+    (iteration files, thresholds, assignments, VCF, stdout), equal to 1e-9 for the per-locus f64 contribution sums (their
+    summation order follows the shard count)."""
+    _, alt, ref, bc, gt, vcf = _write_inputs(str(tmp_path), 1500, 700, 0.12, seed=4, minority=0.08)
+    outs, stdouts = [], []
+    for name, extra in (("one", ["--device", "0"]), ("three", ["--devices", "0,0,0"])):
+        out = str(tmp_path / name)
+        r = subprocess.run([host_bin, "-a", alt, "-r", ref, "--output_directory", out, "--min_alt", "4", "--min_ref", "4",
+                            "--barcodes", bc, "--vcf", vcf, "-g", gt] + extra, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        outs.append(out)
+        stdouts.append(r.stdout)
+    assert stdouts[0] == stdouts[1]
+    files = sorted(os.listdir(outs[0]))
+    assert files == sorted(os.listdir(outs[1])) and "cellector.vcf" in files and "iteration_1.tsv" in files
+    for f in files:
+        a, b = open(os.path.join(outs[0], f)).read(), open(os.path.join(outs[1], f)).read()
+        if not f.endswith("_locus_contribution.tsv"):
+            assert a == b, f
+            continue
+        ra = {ln.split("\t")[0]: ln.split("\t") for ln in a.splitlines()[1:]}
+        rb = {ln.split("\t")[0]: ln.split("\t") for ln in b.splitlines()[1:]}
+        assert ra.keys() == rb.keys()
+        for k, x in ra.items():
+            y = rb[k]
+            assert x[1:3] == y[1:3] and x[7:9] == y[7:9] and x[11:15] == y[11:15], (f, k)
+            for i in (3, 4, 5, 6, 9, 10, 15, 16):
+                assert abs(float(x[i]) - float(y[i])) <= 1e-9 * max(1.0, abs(float(x[i]))), (f, k, i)
+    r = subprocess.run([host_bin, "-a", alt, "-r", ref, "-b", bc, "--output_directory", outs[0], "--device", "0", "--devices", "0"],
+                       capture_output=True, text=True)
+    assert r.returncode != 0 and "cannot be used with" in r.stderr
+
+
+@pytest.mark.gpu
 def test_runtime_errors_exit_nonzero(host_bin, tmp_path):
     _, alt, ref, bc, gt, vcf = _write_inputs(str(tmp_path), 200, 100, 0.2, seed=1, minority=0.1)
     out = str(tmp_path / "o")
