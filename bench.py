@@ -49,6 +49,9 @@ def parse():
                     help="nccl (= RCCL over xGMI, the real path) or gloo: REHEARSAL ONLY — exchanges staged through the host "
                          "so that several ranks can share one GPU (--same-device) on a 1-GPU box")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses cuda:0")
+    ap.add_argument("--exchange", default="lib", choices=["lib", "torch"],
+                    help="N > 1: lib = the library's own RCCL communicator (cellector_comm_init_rank; ncclAllGather / ncclAllReduce "
+                         "enqueued by the C++ loop, the default), torch = torch.distributed collectives on the bound exchange buffers")
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=INT",
                     help="extra cellector_set_option pairs (ablations), e.g. --opt overlap=1")
     ap.add_argument("--no-expected", action="store_true",
@@ -121,16 +124,43 @@ def main():
     per = (N + world - 1) // world
     cb, ce = min(N, rank * per), min(N, (rank + 1) * per)
 
-    g = Cellector(local_rank, stream=torch.cuda.current_stream().cuda_stream)
-    g.set_option("keep_coo", 0)
-    g.set_option("engine", args.engine)
-    g.set_option("compute_expected", 0 if args.no_expected else 1)
-    for kv in args.opt:
-        k, v = kv.split("=")
-        g.set_option(k, int(v))
-    g.set_shard(cb, ce)
-    g.set_option("synth_continue_pct", continue_pct)
-    g.set_option("norm_zero", 0)  # the NORM slices are all-gathered below, not summed: no need to clear the others' first
+    def make_ctx():
+        g = Cellector(local_rank, stream=torch.cuda.current_stream().cuda_stream)
+        g.set_option("keep_coo", 0)
+        g.set_option("engine", args.engine)
+        g.set_option("compute_expected", 0 if args.no_expected else 1)
+        for kv in args.opt:
+            k, v = kv.split("=")
+            g.set_option(k, int(v))
+        g.set_option("synth_continue_pct", continue_pct)
+        return g
+
+    g = make_ctx()
+    # N > 1: the exchanges run inside the library over its own RCCL communicator (rank 0's id is broadcast with the launcher's
+    # process group); if RCCL cannot be set up on any rank, every rank falls back to torch.distributed collectives on the
+    # bound exchange buffers and the line says so.
+    lib_comm = world > 1 and args.exchange == "lib" and args.backend == "nccl"
+    comm_note = None
+    if lib_comm:
+        ok, why = 1, ""
+        try:
+            uid = torch.zeros(128, dtype=torch.uint8, device=dev)
+            if rank == 0:
+                uid.copy_(torch.frombuffer(bytearray(ffi.comm_unique_id()), dtype=torch.uint8))
+            dist.broadcast(uid, 0)
+            g.comm_init_rank(bytes(uid.cpu().numpy().tobytes()), world, rank)
+        except Exception as e:  # noqa: BLE001
+            ok, why = 0, str(e)
+        flag = torch.tensor([float(ok)], dtype=torch.float64, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if flag.item() < 1.0:
+            comm_note = "library communicator unavailable (%s): torch.distributed exchanges" % (why or "another rank failed")
+            lib_comm = False
+            g.close()
+            g = make_ctx()
+    if not lib_comm:
+        g.set_shard(cb, ce)
+        g.set_option("norm_zero", 0)  # the NORM slices are all-gathered below, not summed: no need to clear the others' first
 
     def allreduce(t, op=None):
         if world > 1:
@@ -144,17 +174,24 @@ def main():
 
     # ---- ingest (untimed setup): device-side generation, pass-1 exchange, CSR/CSC build
     t_setup = time.time()
-    x_pass1 = torch.zeros(5 * L_total, dtype=torch.float64, device=dev)
-    g.bind_exchange_buffer(ffi.XCHG_PASS1, x_pass1.data_ptr(), x_pass1.numel())
-    g.ingest_synthetic(L_total, N, density, seed=args.seed, minority_fraction=0.05, doublet_fraction=0.0)
-    allreduce(x_pass1)
-    g.ingest_finish(4, 4)
-    dm = g.dims()
-    L = dm.loci_used
-    x_norm = torch.zeros(world * per, dtype=torch.float64, device=dev)  # padded: every rank owns `per` slots
-    x_locus = torch.zeros(5 * L + 8, dtype=torch.float64, device=dev)
-    g.bind_exchange_buffer(ffi.XCHG_NORM, x_norm.data_ptr(), x_norm.numel())
-    g.bind_exchange_buffer(ffi.XCHG_LOCUS, x_locus.data_ptr(), x_locus.numel())
+    if lib_comm:
+        g.ingest_synthetic(L_total, N, density, seed=args.seed, minority_fraction=0.05, doublet_fraction=0.0)
+        g.ingest_finish(4, 4)  # (all-reduces PASS1 itself)
+        dm = g.dims()
+        L = dm.loci_used
+        assert (dm.cell_begin, dm.cell_end) == (cb, ce)
+    else:
+        x_pass1 = torch.zeros(5 * L_total, dtype=torch.float64, device=dev)
+        g.bind_exchange_buffer(ffi.XCHG_PASS1, x_pass1.data_ptr(), x_pass1.numel())
+        g.ingest_synthetic(L_total, N, density, seed=args.seed, minority_fraction=0.05, doublet_fraction=0.0)
+        allreduce(x_pass1)
+        g.ingest_finish(4, 4)
+        dm = g.dims()
+        L = dm.loci_used
+        x_norm = torch.zeros(world * per, dtype=torch.float64, device=dev)  # padded: every rank owns `per` slots
+        x_locus = torch.zeros(5 * L + 8, dtype=torch.float64, device=dev)
+        g.bind_exchange_buffer(ffi.XCHG_NORM, x_norm.data_ptr(), x_norm.numel())
+        g.bind_exchange_buffer(ffi.XCHG_LOCUS, x_locus.data_ptr(), x_locus.numel())
     torch.cuda.synchronize()
     t_setup = time.time() - t_setup
 
@@ -175,6 +212,8 @@ def main():
             x_norm.copy_(h)
 
     def step():
+        if lib_comm or world == 1:
+            return g.em_iteration(5.0)  # the whole (distributed) iteration inside the library
         g.em_begin()
         exchange_norm()
         g.em_threshold(5.0)
@@ -282,8 +321,12 @@ def main():
                        "step": "one EM iteration = alpha/beta + cell LL pass"
                                + ("" if args.no_expected else " (+expected-log-pmf)")
                                + " + exact quartiles + flags + locus pass + locus filter",
-                       "parallelism": (f"cells/{world}" if world > 1 else "1 gpu")
-                                      + ("" if args.backend == "nccl" else " (gloo host-staged REHEARSAL, not a result)")},
+                       "parallelism": (f"cells/{world}, " + ("RCCL all-gather + all-reduce per iteration inside the library "
+                                                                             "(cellector_comm_init_rank)" if lib_comm else
+                                                                             "torch.distributed exchanges on the bound buffers")
+                                       if world > 1 else "1 gpu")
+                                      + ("" if args.backend == "nccl" else " (gloo host-staged REHEARSAL, not a result)")
+                                      + (f"; {comm_note}" if comm_note else "")},
             "em_iters_per_s": args.steps / elapsed,
             "dense_cells_x_loci_per_s": float(N) * float(L) / (elapsed / args.steps),
             "kernels_ms_note": "breakdown from a second, untimed run of the same steps with every event pair recorded; "

@@ -124,14 +124,15 @@ struct cellector_ctx {
     double *ovf_etab = nullptr;      // [L][8] alpha, beta, E(n) for n = 5..8, pad: the cell side's 64-byte record per locus
     int side_lds = -1;               // option "side_lds": dynamic LDS bytes requested by the cell-side overflow kernel (residency
                                      // throttle; -1 = automatic)
-    bool ovf_locus_pending = false;  // the side stream still owes this iteration's ovf_lp (event ev_join2)
-    double *ovf_lp = nullptr;        // [ovf_n] the EM pass' overflow log-pmfs alone, by-locus order (locus pass)
+    int ovf_deep_opt = -1;           // option "ovf_deep": -1 = decided per matrix (tiled_build), 0 / 1 = forced
+    bool ovf_deep = false;           // the overflow entries are a large share of the matrix (deep coverage): their cell side runs
+                                     // the full form of the direct kernel (totals up to 17 in one kernel), never throttled
+    bool ovf_locus_pending = false;  // the side stream still owes this iteration's locus-side overflow tables (event ev_join2)
     double *ovf_sum = nullptr;       // [3][2][nloc] per-cell sums of the overflow values (ll, expected) per table set
     uint64_t *ovf_ell_ptr = nullptr, *ovf_ell = nullptr;  // 64-row ELLPACK copy of the overflow CSR (cell side): [groups+1], slots
     uint32_t *ovf_tier_row[2] = {nullptr, nullptr};  // the overflow entries with alt+ref in 9..17 (tier 0) / above (tier 1):
     uint64_t *ovf_tier_ent[2] = {nullptr, nullptr};  //   their rows and packed entries, in row order
     uint64_t ovf_n_tier[2] = {0, 0};
-    uint32_t *ovc_locus = nullptr;   // [ovf_n] compact locus index of every overflow entry, by-locus order
     uint32_t *ovf_nmask = nullptr;   // [L] which alt+ref totals (4..17) occur among the locus' overflow entries
     uint64_t *c4_ptr = nullptr;      // [L+1] compact CSC of regular entries
     uint32_t *c4_ent = nullptr;      // 32-bit entries cell_local | code << 28, or 24-bit cell | code << 20 (c4_bits)

@@ -368,10 +368,10 @@ __global__ __launch_bounds__(T_THREADS, 4) void k_tile_ll(uint32_t nb, uint32_t 
 //   cell side   k_ovf_cell_direct: a thread per cell row evaluates the row's overflow entries itself from (alpha, beta) of
 //               their loci (a gather out of an L x 16 B table that stays in L2) and takes the expected terms from a compact
 //               E table (k_ovf_tables_e).  Runs on the side stream beside the tile kernel.
-//   locus side  the locus pass needs every overflow entry's log-pmf in by-locus order: k_ovf_tables (per-locus cumulative
-//               log tables) + k_ovf_values (a thread per entry: lnC + LA[alt] + LB[ref] - LAB[n]) write them to ovf_lp.
-//               Only the EM pass needs them, and only at the locus finalize: they follow the cell side on the side stream
-//               and run beside the end of the tile kernel, the order statistics and the minority kernels.
+//   locus side  the locus pass needs every overflow entry's log-pmf in by-locus order: k_ovf_tables builds per-locus
+//               cumulative log tables, k_locus_finalize evaluates lnC + LA[alt] + LB[ref] - LAB[n] per entry as it walks
+//               the locus (the lanes of a locus share its table row).  Only the EM pass needs the tables, and only at the
+//               locus finalize: the table kernel follows the cell side on the side stream.
 // ---------------------------------------------------------------------------------------------------------
 #define OV_NT 18  // cumulative tables cover counts 0..17; larger counts take the generic device_math path
 #define OV_NE 17  // expected terms E(n) tabulated for n = 4..17
@@ -459,40 +459,6 @@ __global__ __launch_bounds__(256) void k_ovf_tables_e(uint64_t L, const double2 
     if (i >= 1 && i <= 4) etab[l * OV_REC + 2 + (i - 1)] = e;
 }
 
-// one thread per overflow entry, by-locus order: neighbouring threads share a locus, so the three table words an entry
-// needs (LA[alt], LB[ref], LAB[n] of its locus' row) come out of L1; no per-locus loop, no cross-lane traffic
-__global__ __launch_bounds__(256) void k_ovf_values(uint64_t n_ovf, const uint32_t *__restrict__ ovc_locus,
-                                                    const uint64_t *__restrict__ ovc_ent,
-                                                    const double2 *__restrict__ ab, const double *__restrict__ lf,
-                                                    const double *__restrict__ otab, double *__restrict__ lp_out)
-{
-    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n_ovf) return;
-    const uint32_t l = ovc_locus[i];
-    const uint64_t en = ovc_ent[i];
-    const double *row = otab + (uint64_t)l * OV_ROW;
-    double lp = 0.0;
-    if (row[0] >= 0.0) {  // else a masked locus: no PMFData (main.rs:556)
-        const uint32_t a = ENT_ALT(en), r = ENT_REF(en), n = a + r;
-        if (n == 0) lp = 0.0;  // quirk Q14: exactly zero
-        else if (n < (uint32_t)OV_NT) lp = dm_ln_choose(lf, a, r) + (row[a] + row[OV_NT + r] - row[2 * OV_NT + n]);
-        else {
-            const double2 p = ab[l];
-            lp = ov_slow_log_pmf(lf, p.x, p.y, a, r);
-        }
-    }
-    lp_out[i] = lp;
-}
-
-// locus of every overflow entry (by-locus order): wave per locus
-__global__ __launch_bounds__(256) void k_ovf_locus_ids(uint64_t L, const uint64_t *__restrict__ ovc_ptr, uint32_t *__restrict__ ovc_locus)
-{
-    const int lane = threadIdx.x & 63;
-    const uint64_t wave0 = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (uint64_t)gridDim.x * 4;
-    for (uint64_t l = wave0; l < L; l += nwaves)
-        for (uint64_t i = ovc_ptr[l] + lane; i < ovc_ptr[l + 1]; i += 64) ovc_locus[i] = (uint32_t)l;
-}
-
 // nmask[l]: bit (n - 4) set iff an overflow entry of locus l has alt+ref == n, 4 <= n <= OV_NE (static)
 __global__ __launch_bounds__(256) void k_ovf_nmask(uint64_t L, const uint64_t *__restrict__ ovc_ptr,
                                                    const uint64_t *__restrict__ ovc_ent, uint32_t *__restrict__ nmask)
@@ -530,13 +496,18 @@ __global__ __launch_bounds__(256) void k_ovf_nmask(uint64_t L, const uint64_t *_
 // Gathered from two tables an entry fetches two sectors — 2.0 GB per pass at cfg4 on the fabric the tile kernel streams
 // through, 1.0 GB this way.  The variant needs 64 VGPRs, i.e. one wave per SIMD beside the tile kernel: all a big shard's
 // launch asks for (residency throttle, launch_overflow_cell); a small shard wants two and keeps the 48-VGPR form.
-template <bool EXPECTED, bool PACKED>
+// FULL (a matrix whose overflow share is large — deep coverage — runs the kernel with the machine to itself): totals up to
+// OV_NE (17) are taken here too — chunked products, up to three logs, E(n) from the per-locus table — instead of the tier-0
+// list, whose one-thread-per-row walk is built for a handful of entries per row (at 13 % overflow entries that kernel alone
+// took 12 ms of a 21 ms iteration at 1M x 200k).
+template <bool EXPECTED, bool PACKED, bool FULL>
 __global__ __launch_bounds__(256) void k_ovf_cell_direct(
     uint64_t n_rows, const uint64_t *__restrict__ ell_ptr, const uint64_t *__restrict__ ell,
     const double2 *__restrict__ ab, const double *__restrict__ lf, const double *__restrict__ etab,
     const double *__restrict__ otab, double *__restrict__ o_ll, double *__restrict__ o_ell)
 {
     static_assert(EXPECTED || !PACKED, "the record is built for the EM pass");
+    static_assert(!(FULL && PACKED), "the full form runs unthrottled: it takes the unpacked tables");
     const uint64_t row = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (row >= n_rows) return;  // (rows beyond the end have no lane; their slots are padding)
     double s = 0.0, e = 0.0;
@@ -551,7 +522,12 @@ __global__ __launch_bounds__(256) void k_ovf_cell_direct(
         double ev = 0.0;  // (an overflow entry has a total of 0 or above T_K: the record covers T_K + 1 .. OV_FAST_N)
         if (PACKED) ev = n > (uint32_t)T_K && n <= (uint32_t)OV_FAST_N ? rec[n - 3] : 0.0;
         // masked locus: no PMFData (main.rs:556); 0/0 entry: exactly zero (Q14); a total above OV_FAST_N: k_ovf_cell_listed
-        if (!(p.x >= 0.0) || n == 0 || n > (uint32_t)OV_FAST_N) continue;
+        if (!(p.x >= 0.0) || n == 0 || n > (uint32_t)(FULL ? OV_NE : OV_FAST_N)) continue;
+        if (FULL && n > (uint32_t)OV_FAST_N) {  // totals 9..17: the tier-0 arithmetic (k_ovf_cell_listed), in the row's order
+            s += (lf[n] - lf[a] - lf[r]) + dm_log_beta_ratio(p.x, p.y, a, r);
+            if (EXPECTED) e += otab[(uint64_t)l * OV_ROW + OV_EOFF + (n - 4)];
+            continue;
+        }
         // = dm_log_bb_pmf for these totals: ln C out of the factorial table, one log of a ratio of products of <= 8 factors
         const double abs_ = p.x + p.y;
         double num = 1.0, den = 1.0;
@@ -1053,7 +1029,7 @@ __global__ __launch_bounds__(LR_THREADS) void k_minority_ranges(int locus_mode, 
 
 // Outputs of the locus pass from the minority counts (both forms end here, so they agree to the bit).  16 lanes per
 // locus: lane j < 14 takes code j's count (sum of the planes), static histogram and log-pmf; the locus' overflow entries
-// (alt+ref == 0 or > T_K; ~1 %, their log-pmfs stored by k_ovf_values) are walked 16 at a time; per-lane partial results
+// (alt+ref == 0 or > T_K; ~1 %, their log-pmfs evaluated from the locus' cumulative-log row) are walked 16 at a time; per-lane partial results
 // are added by a 4-step butterfly over the 16 lanes (fixed shape: deterministic).
 #define LF_LANES 16
 template <typename T>
@@ -1072,7 +1048,8 @@ __global__ __launch_bounds__(256) void k_locus_finalize(uint64_t L, int locus_mo
                                                         const uint8_t *__restrict__ mask,
                                                         const uint64_t *__restrict__ ovc_ptr /*null: no overflow*/,
                                                         const uint64_t *__restrict__ ovc_ent,
-                                                        const double *__restrict__ ovf_lp, double *__restrict__ out)
+                                                        const double *__restrict__ otab, const double *__restrict__ lf,
+                                                        const double2 *__restrict__ ab, double *__restrict__ out)
 {
     // the minority-driven form left n_sub planes of u16 counts, the streamed form one plane of u32 counts
     const bool by_min = locus_by_minority(locus_mode, *n_min_p, nloc, n_sub);
@@ -1105,7 +1082,10 @@ __global__ __launch_bounds__(256) void k_locus_finalize(uint64_t L, int locus_mo
             cmaj = (double)(h_all - cnt) * t_code;
         }
     }
-    // overflow entries: four independent (entry, value) loads per lane in flight, then their exclusion-bitmask words
+    // overflow entries: four independent entry loads per lane in flight, then their exclusion-bitmask words and their
+    // log-pmfs = lnC + LA[alt] + LB[ref] - LAB[n] out of the locus' cumulative-log row (k_ovf_tables; the 16 lanes share the
+    // row: L1) — evaluated here instead of being stored by a kernel of their own and read back (12 + 8 + 8 bytes per entry)
+    const double *orow = otab + l * OV_ROW;
     for (uint64_t i0 = obeg + j; i0 < oend; i0 += 4 * LF_LANES) {
         uint64_t en[4];
         double lp[4];
@@ -1113,12 +1093,22 @@ __global__ __launch_bounds__(256) void k_locus_finalize(uint64_t L, int locus_mo
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const uint64_t i = i0 + (uint64_t)u * LF_LANES;
-            const bool ok = i < oend;
-            en[u] = ok ? ovc_ent[i] : ~0ull;
-            lp[u] = ok ? ovf_lp[i] : 0.0;
+            en[u] = i < oend ? ovc_ent[i] : ~0ull;
         }
 #pragma unroll
         for (int u = 0; u < 4; u++) w[u] = en[u] != ~0ull ? flag_bits[ENT_IDX(en[u]) >> 5] : 0u;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            lp[u] = 0.0;
+            if (en[u] == ~0ull || !live) continue;  // (a masked locus has no PMFData, main.rs:556: only its tallies count)
+            const uint32_t a = ENT_ALT(en[u]), r = ENT_REF(en[u]), n = a + r;
+            if (n == 0) lp[u] = 0.0;  // quirk Q14: exactly zero
+            else if (n < (uint32_t)OV_NT) lp[u] = dm_ln_choose(lf, a, r) + (orow[a] + orow[OV_NT + r] - orow[2 * OV_NT + n]);
+            else {
+                const double2 p = ab[l];
+                lp[u] = ov_slow_log_pmf(lf, p.x, p.y, a, r);
+            }
+        }
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             if (en[u] == ~0ull) continue;
@@ -1414,7 +1404,7 @@ void tiled_free(cellector_ctx *c)
     dev_free(c->c4_ptr); dev_free(c->c4_ent); dev_free(c->ovc_ptr); dev_free(c->ovc_ent);
     dev_free(c->hist_all); dev_free(c->tab); dev_free(c->part); dev_free(c->ab3);
     dev_free(c->masked_cnt); dev_free(c->flag_bits); dev_free(c->ovf_tab); dev_free(c->ovf_etab);
-    dev_free(c->ovf_sum); dev_free(c->ovf_lp); dev_free(c->ovc_locus); dev_free(c->ovf_tier_row[0]); dev_free(c->ovf_tier_row[1]); dev_free(c->ovf_tier_ent[0]); dev_free(c->ovf_tier_ent[1]); dev_free(c->ovf_ell_ptr); dev_free(c->ovf_ell); dev_free(c->ovf_nmask); dev_free(c->tile_work); dev_free(c->minlist); dev_free(c->hist_min); dev_free(c->roff); dev_free(c->c4r); dev_free(c->mroff); dev_free(c->mbeg);
+    dev_free(c->ovf_sum); dev_free(c->ovf_tier_row[0]); dev_free(c->ovf_tier_row[1]); dev_free(c->ovf_tier_ent[0]); dev_free(c->ovf_tier_ent[1]); dev_free(c->ovf_ell_ptr); dev_free(c->ovf_ell); dev_free(c->ovf_nmask); dev_free(c->tile_work); dev_free(c->minlist); dev_free(c->hist_min); dev_free(c->roff); dev_free(c->c4r); dev_free(c->mroff); dev_free(c->mbeg);
     c->mroff_cap = 0;
     c->tiled_ready = false;
     c->ovf_n = 0; c->n_masked_loci = 0;
@@ -1548,11 +1538,9 @@ cellector_status tiled_build(cellector_ctx *c)
     // ---- overflow values: by-locus storage + permutation for the by-cell gather
     if (c->ovf_n >= (1ull << 32)) return ctx_fail(c, CELLECTOR_EINVAL, "tiled engine: more than 2^32 overflow entries per shard");
     CHK(dev_alloc(c, &c->ovf_sum, 3 * 2 * nloc));
-    CHK(dev_alloc(c, &c->ovf_lp, c->ovf_n));
     CHK(dev_alloc(c, &c->ovf_tab, L * OV_ROW));
     CHK(dev_alloc(c, &c->ovf_etab, L * OV_REC));
     CHK(dev_alloc(c, &c->ovf_nmask, L));
-    CHK(dev_alloc(c, &c->ovc_locus, c->ovf_n));
     {
         const uint64_t n_grp = (nloc + 63) / 64;
         uint64_t slots = 0;
@@ -1594,8 +1582,6 @@ cellector_status tiled_build(cellector_ctx *c)
         CHK(st);
     }
     if (L && c->ovf_n)
-        hipLaunchKernelGGL(k_ovf_locus_ids, dim3(gcap(L, 4)), dim3(256), 0, c->stream, L, c->ovc_ptr, c->ovc_locus);
-    if (L && c->ovf_n)
         hipLaunchKernelGGL(k_ovf_nmask, dim3(gcap(L, 4)), dim3(256), 0, c->stream, L, c->ovc_ptr, c->ovc_ent, c->ovf_nmask);
     HIPCHK(c, hipGetLastError());
 
@@ -1635,6 +1621,9 @@ cellector_status tiled_build(cellector_ctx *c)
     HIPCHK(c, hipMemsetAsync(c->masked_cnt, 0, (nloc ? nloc : 1) * 4, c->stream));
     HIPCHK(c, hipMemsetAsync(c->flag_bits, 0, ((nloc + 31) / 32 + 1) * 4, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    // deep coverage: more than 3 % of the entries outside the tables (0.8 % with vartrix-like totals 1 + Geometric(0.7),
+    // 13 % with 1 + Geometric(0.4)) — the side-stream arrangement built for "a few entries per row" no longer hides them
+    c->ovf_deep = c->ovf_deep_opt >= 0 ? c->ovf_deep_opt != 0 : (c->ovf_n * 100 > c->nnz * 3);
     c->tiled_ready = true;
     return CELLECTOR_OK;
 }
@@ -1646,28 +1635,36 @@ static void launch_overflow_cell(cellector_ctx *c, hipStream_t st, const double2
 {
     double *o_ll = c->ovf_sum + (uint64_t)set * 2 * c->nloc, *o_ell = o_ll + c->nloc;
     const unsigned g = gcap(c->nloc, 256, 0x7fffffffu), eg = gcap(c->L * 16, 256, 0x7fffffffu);
+    const bool deep = c->ovf_deep;  // the overflow share is large: full form, never throttled, no tier-0 list
     if (expected) {
         hipLaunchKernelGGL(k_ovf_tables_e, dim3(eg), dim3(256), 0, st, c->L, ab, c->ovf_nmask, c->ovf_tab, c->ovf_etab);
         // Residency throttle: a request for dynamic LDS it does not use leaves room for only ONE block of this kernel beside
         // a tile workgroup (one wave per SIMD instead of two).  On a big shard the kernel still ends well inside the tile
         // kernel and disturbs it less (cfg4: 2.83 -> 2.78 ms per iteration); a small shard's tile kernel is too short for that.
-        const size_t lds_req = c->side_lds >= 0 ? (size_t)c->side_lds : (st == c->side && c->nloc >= (1ull << 19) ? 5000 : 0);
-        if (lds_req)  // one block per CU: the 64-VGPR form with the packed per-locus record
-            hipLaunchKernelGGL((k_ovf_cell_direct<true, true>), dim3(g), dim3(256), lds_req, st, c->nloc, c->ovf_ell_ptr, c->ovf_ell,
+        const size_t lds_req = deep ? 0 : c->side_lds >= 0 ? (size_t)c->side_lds : (st == c->side && c->nloc >= (1ull << 19) ? 5000 : 0);
+        if (deep)
+            hipLaunchKernelGGL((k_ovf_cell_direct<true, false, true>), dim3(g), dim3(256), 0, st, c->nloc, c->ovf_ell_ptr, c->ovf_ell, ab,
+                               c->lf, c->ovf_etab, c->ovf_tab, o_ll, o_ell);
+        else if (lds_req)  // one block per CU: the 64-VGPR form with the packed per-locus record
+            hipLaunchKernelGGL((k_ovf_cell_direct<true, true, false>), dim3(g), dim3(256), lds_req, st, c->nloc, c->ovf_ell_ptr, c->ovf_ell,
                                ab, c->lf, c->ovf_etab, c->ovf_tab, o_ll, o_ell);
         else
-            hipLaunchKernelGGL((k_ovf_cell_direct<true, false>), dim3(g), dim3(256), 0, st, c->nloc, c->ovf_ell_ptr, c->ovf_ell, ab,
+            hipLaunchKernelGGL((k_ovf_cell_direct<true, false, false>), dim3(g), dim3(256), 0, st, c->nloc, c->ovf_ell_ptr, c->ovf_ell, ab,
                                c->lf, c->ovf_etab, c->ovf_tab, o_ll, o_ell);
-        if (c->ovf_n_tier[0])
+        if (c->ovf_n_tier[0] && !deep)
             hipLaunchKernelGGL((k_ovf_cell_listed<true, false>), dim3(gcap(c->ovf_n_tier[0], 256, 0x7fffffffu)), dim3(256), 0, st,
                                c->ovf_n_tier[0], c->ovf_tier_row[0], c->ovf_tier_ent[0], ab, c->lf, c->ovf_tab, o_ll, o_ell);
         if (c->ovf_n_tier[1])
             hipLaunchKernelGGL((k_ovf_cell_listed<true, true>), dim3(gcap(c->ovf_n_tier[1], 256, 0x7fffffffu)), dim3(256), 0, st,
                                c->ovf_n_tier[1], c->ovf_tier_row[1], c->ovf_tier_ent[1], ab, c->lf, c->ovf_tab, o_ll, o_ell);
     } else {
-        hipLaunchKernelGGL((k_ovf_cell_direct<false, false>), dim3(g), dim3(256), 0, st, c->nloc, c->ovf_ell_ptr, c->ovf_ell, ab, c->lf,
-                           c->ovf_etab, c->ovf_tab, o_ll, o_ell);
-        if (c->ovf_n_tier[0])
+        if (deep)
+            hipLaunchKernelGGL((k_ovf_cell_direct<false, false, true>), dim3(g), dim3(256), 0, st, c->nloc, c->ovf_ell_ptr, c->ovf_ell, ab, c->lf,
+                               c->ovf_etab, c->ovf_tab, o_ll, o_ell);
+        else
+            hipLaunchKernelGGL((k_ovf_cell_direct<false, false, false>), dim3(g), dim3(256), 0, st, c->nloc, c->ovf_ell_ptr, c->ovf_ell, ab, c->lf,
+                               c->ovf_etab, c->ovf_tab, o_ll, o_ell);
+        if (c->ovf_n_tier[0] && !deep)
             hipLaunchKernelGGL((k_ovf_cell_listed<false, false>), dim3(gcap(c->ovf_n_tier[0], 256, 0x7fffffffu)), dim3(256), 0, st,
                                c->ovf_n_tier[0], c->ovf_tier_row[0], c->ovf_tier_ent[0], ab, c->lf, c->ovf_tab, o_ll, o_ell);
         if (c->ovf_n_tier[1])
@@ -1675,12 +1672,10 @@ static void launch_overflow_cell(cellector_ctx *c, hipStream_t st, const double2
                                c->ovf_n_tier[1], c->ovf_tier_row[1], c->ovf_tier_ent[1], ab, c->lf, c->ovf_tab, o_ll, o_ell);
     }
 }
-// locus side: the overflow entries' log-pmfs in by-locus order (ovf_lp), on stream `st`
+// locus side: the per-locus cumulative-log tables that k_locus_finalize evaluates the overflow entries' log-pmfs from, on stream `st`
 static void launch_overflow_locus_values(cellector_ctx *c, hipStream_t st, const double2 *ab)
 {
     hipLaunchKernelGGL(k_ovf_tables, dim3(gcap(c->L * 3, 256, 0x7fffffffu)), dim3(256), 0, st, c->L, ab, c->ovf_nmask, c->ovf_tab);
-    hipLaunchKernelGGL(k_ovf_values, dim3(gcap(c->ovf_n, 256, 0x7fffffffu)), dim3(256), 0, st, c->ovf_n, c->ovc_locus, c->ovc_ent, ab,
-                       c->lf, c->ovf_tab, c->ovf_lp);
 }
 
 static bool have_overflow(const cellector_ctx *c) { return c->ovf_n != 0 && c->L != 0 && c->nloc != 0; }
@@ -1882,7 +1877,7 @@ cellector_status tiled_locus_pass(cellector_ctx *c)
     hipLaunchKernelGGL(k_locus_finalize, dim3(gcap(c->L * LF_LANES, 256, 0x7fffffffu)), dim3(256), 0, c->stream, c->L, c->locus_mode,
                        c->nloc, c->lr_sub, c->d_counters + DC_N_MIN, c->hist_min, c->flag_bits, c->hist_all, c->tab_em,
                        (uint32_t)c->tab_em_stride, c->mask, c->ovf_n ? c->ovc_ptr : (const uint64_t *)nullptr, c->ovc_ent,
-                       c->ovf_lp, c->x_locus);
+                       c->ovf_tab, c->lf, c->ab, c->x_locus);
     timer_end(c, CELLECTOR_K_LOCUS_STATS);
     HIPCHK(c, hipGetLastError());
     return CELLECTOR_OK;

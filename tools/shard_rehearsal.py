@@ -20,7 +20,7 @@ def main():
     import torch
     from bench import WORKLOADS
     from cellector_amd import Cellector, ffi
-    N, L_total, density = WORKLOADS[args.workload]
+    N, L_total, density, _pct = WORKLOADS[args.workload]
     dev = torch.device("cuda", 0)
     out = []
     for R in [int(x) for x in args.ranks.split(",")]:
