@@ -1772,7 +1772,9 @@ cellector_status tiled_cell_pass(cellector_ctx *c, const double2 *ab, double *no
     // waits for them (tiled_locus_pass).  (overlap 0: everything in the main stream.)
     if (for_em && c->tables_prebuilt) c->tables_prebuilt = false;  // built ahead by the previous iteration's em_finish
     else CHK(build_tile_tables(c, ab, 0, c->compute_expected, for_em));
-    if (ovf && c->overlap) {
+    // (deep coverage: the overflow entries are too many to hide in the tile kernel's spare wave slots — their kernel runs
+    //  with the machine to itself, in the main stream: cfg3-deep 1.93 ms per iteration against 2.32 beside the tile kernel)
+    if (ovf && c->overlap && !c->ovf_deep) {
         // the tile kernel is launched FIRST: with the tables built ahead the queue is empty when the host gets here, and
         // every launch ahead of it (five on the side stream) would be ~10 us of idle GPU
         CHK(side_fork(c));
@@ -1922,7 +1924,7 @@ cellector_status tiled_posteriors(cellector_ctx *c, double mf0, double lp_min, d
     timer_begin(c, CELLECTOR_K_POSTERIOR);
     const bool ovf = have_overflow(c);
     for (int set = 0; set < 3; set++) CHK(build_tile_tables(c, c->ab3 + (uint64_t)set * L, set, false));
-    if (ovf && c->overlap) {
+    if (ovf && c->overlap && !c->ovf_deep) {
         CHK(side_fork(c));
         for (int set = 0; set < 3; set++) launch_overflow_cell(c, c->side, c->ab3 + (uint64_t)set * L, set, false);
         for (int set = 0; set < 3; set++) CHK(run_tile_pass(c, set, false));
