@@ -390,7 +390,10 @@ static cellector_status begin_ingest(cellector_ctx *c, uint64_t total_loci, uint
     REQUIRE(c, total_loci <= 0xffffffffull && total_cells <= 0xffffffffull, "dims exceed 32-bit indices");
     c->total_loci = total_loci;
     c->total_cells = total_cells;
-    if (comm_active(c->comm)) {  // rank r owns the r-th of n equal contiguous ranges (the NORM all-gather needs equal slots)
+    if (c->ingest_all_cells) {
+        c->cell_begin = 0;
+        c->cell_end = total_cells;
+    } else if (comm_active(c->comm)) {  // rank r owns the r-th of n equal contiguous ranges (the NORM all-gather needs equal slots)
         const uint64_t per = comm_cells_per_rank(total_cells, c->comm.n);
         c->cell_begin = std::min(total_cells, (uint64_t)c->comm.rank * per);
         c->cell_end = std::min(total_cells, c->cell_begin + per);
@@ -452,6 +455,37 @@ cellector_status cellector_ingest_mtx(cellector_ctx *c, const char *alt_path, co
     c->state = cellector_ctx::ST_STAGED;
     return CELLECTOR_OK;
 }
+
+}  // extern "C"
+
+// Multi-device text ingest, step 1: shard `c` tokenises the whole pair and stages the entries of ALL cells (global cell index).
+cellector_status ffi_stage_mtx_all_cells(cellector_ctx *c, const char *alt_path, const char *ref_path)
+{
+    REQUIRE(c, alt_path && ref_path, "null path");
+    MtxInput *in = nullptr;
+    uint64_t tl = 0, tc = 0;
+    CHK(mtx_input_open(c, alt_path, ref_path, &in, &tl, &tc));
+    c->ingest_all_cells = true;
+    cellector_status s = begin_ingest(c, tl, tc);
+    if (s == CELLECTOR_OK) s = ingest_stage_mtx_device(c, in);
+    c->ingest_all_cells = false;
+    mtx_input_close(in);
+    return s;
+}
+// ... step 2: a shard takes over its routed entries (arrays on its own device, cell index local, file order) as its staged COO.
+cellector_status ffi_adopt_staged(cellector_ctx *c, uint64_t total_loci, uint64_t total_cells, uint32_t *locus, uint32_t *cell,
+                                  uint16_t *alt, uint16_t *ref, uint64_t n, bool sorted)
+{
+    CHK(begin_ingest(c, total_loci, total_cells));
+    c->coo_locus = locus; c->coo_cell = cell; c->coo_alt = alt; c->coo_ref = ref;
+    c->coo_n = n;
+    c->coo_sorted = sorted;
+    CHK(ingest_pass1(c));
+    c->state = cellector_ctx::ST_STAGED;
+    return CELLECTOR_OK;
+}
+
+extern "C" {
 
 cellector_status cellector_ingest_synthetic(cellector_ctx *c, uint64_t total_loci, uint64_t total_cells,
                                             double density, uint64_t seed, double minority_fraction,

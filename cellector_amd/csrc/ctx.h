@@ -52,6 +52,7 @@ struct cellector_ctx {
     // the exchange transport of a shard that is part of a sharded run (n = 1: single shard, nothing is exchanged)
     Comm comm;
     bool owns_stream = false;  // the stream was created by the library (a shard of a root ctx)
+    bool ingest_all_cells = false;  // begin_ingest: this shard stages ALL cells for now (multi-device text ingest parses once)
     int device = 0;
     hipStream_t stream = nullptr;
     // side stream for the small overflow kernels that run next to the tile kernel (fork/join with events)
@@ -250,6 +251,12 @@ cellector_status select_threshold(cellector_ctx *c, const double *keys, uint64_t
 cellector_status ingest_stage_host_coo(cellector_ctx *c, uint64_t nnz, const uint32_t *locus0,
                                        const uint32_t *cell0, const uint32_t *alt, const uint32_t *ref);
 cellector_status ingest_pass1(cellector_ctx *c);
+cellector_status ingest_split_coo(cellector_ctx *src, uint64_t cb, uint64_t ce, uint64_t *keep, uint32_t **o_locus, uint32_t **o_cell,
+                                  uint16_t **o_alt, uint16_t **o_ref, uint64_t *n_out);
+// multi-device text ingest (cellector_ffi.cpp): stage the whole pair on one shard / hand a shard its routed entries
+cellector_status ffi_stage_mtx_all_cells(cellector_ctx *c, const char *alt_path, const char *ref_path);
+cellector_status ffi_adopt_staged(cellector_ctx *c, uint64_t total_loci, uint64_t total_cells, uint32_t *locus, uint32_t *cell,
+                                  uint16_t *alt, uint16_t *ref, uint64_t n, bool sorted);
 cellector_status ingest_build(cellector_ctx *c, uint64_t min_alt, uint64_t min_ref);
 cellector_status synth_generate(cellector_ctx *c, double density, uint64_t seed, double minority_fraction,
                                 double doublet_fraction);

@@ -295,6 +295,53 @@ cellector_status ingest_stage_host_coo(cellector_ctx *c, uint64_t nnz, const uin
     return CELLECTOR_OK;
 }
 
+// ---- an all-cells staged COO cut by cell range (multi-device text ingest: the pair is parsed ONCE, its entries routed to
+// the shard that owns their cell; file order is kept inside every shard) ---------------------------------------------------
+__global__ __launch_bounds__(256) void k_coo_in_range(uint64_t n, const uint32_t *__restrict__ cell, uint64_t cb, uint64_t ce,
+                                                      uint64_t *__restrict__ keep /*[n + 1]*/)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i > n) return;
+    keep[i] = (i < n && cell[i] >= cb && cell[i] < ce) ? 1ull : 0ull;
+}
+__global__ __launch_bounds__(256) void k_coo_take_range(uint64_t n, const uint32_t *__restrict__ locus, const uint32_t *__restrict__ cell,
+                                                        const uint16_t *__restrict__ alt, const uint16_t *__restrict__ ref, uint64_t cb,
+                                                        uint64_t ce, const uint64_t *__restrict__ pos, uint32_t *__restrict__ o_locus,
+                                                        uint32_t *__restrict__ o_cell, uint16_t *__restrict__ o_alt,
+                                                        uint16_t *__restrict__ o_ref)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t c0 = cell[i];
+    if (c0 < cb || c0 >= ce) return;
+    const uint64_t p = pos[i];
+    o_locus[p] = locus[i];
+    o_cell[p] = (uint32_t)(c0 - cb);
+    o_alt[p] = alt[i];
+    o_ref[p] = ref[i];
+}
+// src holds the staged COO of ALL cells (cell index global).  Writes the entries of cells [cb, ce) — cell index made local,
+// order kept — into four new arrays on src's device; `keep` is caller scratch of n + 1 words.
+cellector_status ingest_split_coo(cellector_ctx *src, uint64_t cb, uint64_t ce, uint64_t *keep, uint32_t **o_locus, uint32_t **o_cell,
+                                  uint16_t **o_alt, uint16_t **o_ref, uint64_t *n_out)
+{
+    const uint64_t n = src->coo_n;
+    const unsigned g = (unsigned)((n + 1 + 255) / 256);
+    hipLaunchKernelGGL(k_coo_in_range, dim3(g), dim3(256), 0, src->stream, n, src->coo_cell, cb, ce, keep);
+    HIPCHK(src, hipGetLastError());
+    uint64_t kept = 0;
+    CHK(dev_exclusive_scan_u64(src, keep, n + 1, &kept));
+    CHK(dev_alloc(src, o_locus, kept)); CHK(dev_alloc(src, o_cell, kept));
+    CHK(dev_alloc(src, o_alt, kept)); CHK(dev_alloc(src, o_ref, kept));
+    if (n)
+        hipLaunchKernelGGL(k_coo_take_range, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, src->stream, n, src->coo_locus, src->coo_cell,
+                           src->coo_alt, src->coo_ref, cb, ce, keep, *o_locus, *o_cell, *o_alt, *o_ref);
+    HIPCHK(src, hipGetLastError());
+    HIPCHK(src, hipStreamSynchronize(src->stream));
+    *n_out = kept;
+    return CELLECTOR_OK;
+}
+
 cellector_status ingest_pass1(cellector_ctx *c)
 {
     const uint64_t TL = c->total_loci;

@@ -5,6 +5,7 @@
 // once (logical shards on one GPU: tests and one-GPU rehearsals; RCCL refuses duplicate devices).  Every public entry point
 // called on the root fans out to the shards on their worker threads; the shards run the same code as a single-GPU ctx, with
 // the three exchanges (PASS1 / NORM / LOCUS) done inside the library.
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <cstdio>
@@ -172,11 +173,71 @@ cellector_status multi_set_option(cellector_ctx *root, const char *key, int64_t 
 
 // ---- ingest ------------------------------------------------------------------------------------------------------------------
 // (every shard sets its own canonical cell range in begin_ingest: a shard with a communicator ignores cellector_set_shard)
+// The text pair is read, uploaded and tokenised ONCE, on shard 0's device; its entries are then cut by owning cell range
+// (file order kept) and every piece goes to its shard's device (peer copy over xGMI; a plain device copy between logical
+// shards of one GPU).  n shards each parsing the whole pair would read the text n times on the host and push it over n PCIe
+// links at once: slower than one GPU from a few shards on.  (Parsing 1/n of the bytes per GPU is the scalable form — it
+// needs the two files' line numbers matched across byte ranges — and is not built.)
 cellector_status multi_ingest_mtx(cellector_ctx *root, const char *alt_path, const char *ref_path)
 {
-    // every shard reads the pair and keeps its own cells (the device-side shard filter of the parser); the text goes to each
-    // GPU over that GPU's own PCIe link
-    return run_all(root, [=](cellector_ctx *s, int) { return cellector_ingest_mtx(s, alt_path, ref_path); });
+    MultiCtx *m = root->multi;
+    if (getenv("CELLECTOR_MULTI_PARSE_EACH"))  // (A/B: every shard parses the pair itself)
+        return run_all(root, [=](cellector_ctx *s, int) { return cellector_ingest_mtx(s, alt_path, ref_path); });
+    cellector_ctx *s0 = m->shards[0];
+    auto fail = [&](cellector_ctx *s, cellector_status st) {
+        root->err = "shard (device " + std::to_string(s->device) + "): " + s->err;
+        return st;
+    };
+    if (hipSetDevice(s0->device) != hipSuccess) return ctx_fail(root, CELLECTOR_EDEVICE, "hipSetDevice failed");
+    cellector_status st = ffi_stage_mtx_all_cells(s0, alt_path, ref_path);
+    if (st != CELLECTOR_OK) return fail(s0, st);
+    // detach the all-cells arrays from shard 0 (its own piece is cut from them like the others')
+    cellector_ctx all;  // (a plain holder: no device state of its own is created or destroyed)
+    all.device = s0->device; all.stream = s0->stream;
+    all.coo_locus = s0->coo_locus; all.coo_cell = s0->coo_cell; all.coo_alt = s0->coo_alt; all.coo_ref = s0->coo_ref;
+    all.coo_n = s0->coo_n;
+    const bool sorted = s0->coo_sorted;
+    const uint64_t TL = s0->total_loci, TC = s0->total_cells;
+    s0->coo_locus = s0->coo_cell = nullptr; s0->coo_alt = s0->coo_ref = nullptr; s0->coo_n = 0;
+    uint64_t *keep = nullptr;
+    st = dev_alloc(&all, &keep, all.coo_n + 1);
+    const int n = (int)m->shards.size();
+    const uint64_t per = comm_cells_per_rank(TC, n);
+    for (int r = 0; r < n && st == CELLECTOR_OK; r++) {
+        cellector_ctx *s = m->shards[(size_t)r];
+        const uint64_t cb = std::min(TC, (uint64_t)r * per), ce = std::min(TC, cb + per);
+        uint32_t *pl = nullptr, *pc = nullptr;
+        uint16_t *pa = nullptr, *pr = nullptr;
+        uint64_t cnt = 0;
+        (void)hipSetDevice(all.device);
+        st = ingest_split_coo(&all, cb, ce, keep, &pl, &pc, &pa, &pr, &cnt);
+        if (st != CELLECTOR_OK) { root->err = all.err; break; }
+        if (s->device != all.device) {  // move the piece to the shard's device
+            uint32_t *ql = nullptr, *qc = nullptr;
+            uint16_t *qa = nullptr, *qr = nullptr;
+            (void)hipSetDevice(s->device);
+            st = dev_alloc(s, &ql, cnt);
+            if (st == CELLECTOR_OK) st = dev_alloc(s, &qc, cnt);
+            if (st == CELLECTOR_OK) st = dev_alloc(s, &qa, cnt);
+            if (st == CELLECTOR_OK) st = dev_alloc(s, &qr, cnt);
+            if (st == CELLECTOR_OK && cnt &&
+                (hipMemcpyPeer(ql, s->device, pl, all.device, cnt * 4) != hipSuccess || hipMemcpyPeer(qc, s->device, pc, all.device, cnt * 4) != hipSuccess ||
+                 hipMemcpyPeer(qa, s->device, pa, all.device, cnt * 2) != hipSuccess || hipMemcpyPeer(qr, s->device, pr, all.device, cnt * 2) != hipSuccess))
+                st = ctx_fail(s, CELLECTOR_EDEVICE, "peer copy of the shard's entries failed: %s", hipGetErrorString(hipGetLastError()));
+            (void)hipSetDevice(all.device);
+            dev_free(pl); dev_free(pc); dev_free(pa); dev_free(pr);
+            if (st != CELLECTOR_OK) { dev_free(ql); dev_free(qc); dev_free(qa); dev_free(qr); fail(s, st); break; }
+            pl = ql; pc = qc; pa = qa; pr = qr;
+        }
+        (void)hipSetDevice(s->device);
+        st = ffi_adopt_staged(s, TL, TC, pl, pc, pa, pr, cnt, sorted);
+        if (st != CELLECTOR_OK) fail(s, st);
+    }
+    (void)hipSetDevice(all.device);
+    dev_free(keep);
+    dev_free(all.coo_locus); dev_free(all.coo_cell); dev_free(all.coo_alt); dev_free(all.coo_ref);
+    all.stream = nullptr;
+    return st;
 }
 cellector_status multi_ingest_coo(cellector_ctx *root, uint64_t total_loci, uint64_t total_cells, uint64_t nnz, const uint32_t *locus0,
                                   const uint32_t *cell0, const uint32_t *alt, const uint32_t *ref)

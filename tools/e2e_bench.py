@@ -32,6 +32,7 @@ def main():
     ap.add_argument("--device-writer", action="store_true",
                     help="format the text files on the device (cellector_write_staged_mtx): for BASELINE-sized inputs")
     ap.add_argument("--tmp", default=None, help="directory for the input / output files (default: a temp dir)")
+    ap.add_argument("--devices", default=None, help="passed to host/cellector as --devices (e.g. 0,0,0,0: logical shards of GPU 0)")
     args = ap.parse_args()
     import ctypes
     from cellector_amd import Cellector, synth
@@ -80,6 +81,8 @@ def main():
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "host"), "-s"])
     cmd = [os.path.join(ROOT, "host", "cellector"), "-a", paths["alt"], "-r", paths["ref"], "--output_directory", out_dir,
            "--min_alt", "4", "--min_ref", "4", "--barcodes", bc, "--vcf", vcf, "--min_alleles_posterior", "5"]
+    if args.devices:
+        cmd += ["--devices", args.devices]
     times = []
     for _ in range(2):  # second run: page cache and driver warm, like the oracle's files
         t0 = time.perf_counter()
@@ -92,7 +95,7 @@ def main():
     res = {"workload": f"{N} cells x {L} loci, density {args.density}: text .mtx pair + barcodes + VCF -> all TSVs + cellector.vcf",
            "entries": n_entries, "text_bytes": int(sum(os.path.getsize(p) for p in paths.values())),
            "inputs_written_s": t_write, "device_writer": bool(args.device_writer),
-           "em_iterations": n_iter, "output_bytes": int(out_bytes),
+           "em_iterations": n_iter, "output_bytes": int(out_bytes), "devices": args.devices,
            "gpu_cli_wall_s": times[1], "gpu_cli_first_run_s": times[0], "gpu_cli_phases": phases}
     if not args.no_oracle:
         from oracle import binding as ob
