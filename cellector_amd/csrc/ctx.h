@@ -128,7 +128,9 @@ struct cellector_ctx {
     int ovf_deep_opt = -1;           // option "ovf_deep": -1 = decided per matrix (tiled_build), 0 / 1 = forced
     bool ovf_deep = false;           // the overflow entries are a large share of the matrix (deep coverage): their cell side runs
                                      // the full form of the direct kernel (totals up to 17 in one kernel), never throttled
-    bool ovf_locus_pending = false;  // the side stream still owes this iteration's locus-side overflow tables (event ev_join2)
+    bool ovf_locus_pending = false;  // the side stream still owes this iteration's locus-side overflow tables / values (event ev_join2)
+    double *ovf_lp = nullptr;        // [ovf_n] shallow coverage: the EM pass' overflow log-pmfs, by-locus order (k_ovf_values -> k_locus_finalize)
+    uint32_t *ovc_locus = nullptr;   // [ovf_n] compact locus index of every overflow entry, by-locus order (k_ovf_values)
     double *ovf_sum = nullptr;       // [3][2][nloc] per-cell sums of the overflow values (ll, expected) per table set
     uint64_t *ovf_ell_ptr = nullptr, *ovf_ell = nullptr;  // 64-row ELLPACK copy of the overflow CSR (cell side): [groups+1], slots
     uint32_t *ovf_tier_row[2] = {nullptr, nullptr};  // the overflow entries with alt+ref in 9..17 (tier 0) / above (tier 1):

@@ -459,6 +459,42 @@ __global__ __launch_bounds__(256) void k_ovf_tables_e(uint64_t L, const double2 
     if (i >= 1 && i <= 4) etab[l * OV_REC + 2 + (i - 1)] = e;
 }
 
+// The overflow entries' log-pmfs in by-locus order for the locus finalize, shallow-coverage form: a thread per entry
+// (neighbouring threads share a locus: the three table words an entry needs come out of L1), on the side stream beside the
+// tile kernel; the finalize then reads 8 bytes per entry.  (A deep-coverage matrix, ovf_deep, evaluates them inside
+// k_locus_finalize instead: storing and re-reading 2.6e8 values was 4 GB of traffic per iteration at 1M x 200k.)
+__global__ __launch_bounds__(256) void k_ovf_values(uint64_t n_ovf, const uint32_t *__restrict__ ovc_locus,
+                                                    const uint64_t *__restrict__ ovc_ent,
+                                                    const double2 *__restrict__ ab, const double *__restrict__ lf,
+                                                    const double *__restrict__ otab, double *__restrict__ lp_out)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_ovf) return;
+    const uint32_t l = ovc_locus[i];
+    const uint64_t en = ovc_ent[i];
+    const double *row = otab + (uint64_t)l * OV_ROW;
+    double lp = 0.0;
+    if (row[0] >= 0.0) {  // else a masked locus: no PMFData (main.rs:556)
+        const uint32_t a = ENT_ALT(en), r = ENT_REF(en), n = a + r;
+        if (n == 0) lp = 0.0;  // quirk Q14: exactly zero
+        else if (n < (uint32_t)OV_NT) lp = (lf[n] - lf[a] - lf[r]) + (row[a] + row[OV_NT + r] - row[2 * OV_NT + n]);
+        else {
+            const double2 p = ab[l];
+            lp = ov_slow_log_pmf(lf, p.x, p.y, a, r);
+        }
+    }
+    lp_out[i] = lp;
+}
+
+// locus of every overflow entry (by-locus order): wave per locus
+__global__ __launch_bounds__(256) void k_ovf_locus_ids(uint64_t L, const uint64_t *__restrict__ ovc_ptr, uint32_t *__restrict__ ovc_locus)
+{
+    const int lane = threadIdx.x & 63;
+    const uint64_t wave0 = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (uint64_t)gridDim.x * 4;
+    for (uint64_t l = wave0; l < L; l += nwaves)
+        for (uint64_t i = ovc_ptr[l] + lane; i < ovc_ptr[l + 1]; i += 64) ovc_locus[i] = (uint32_t)l;
+}
+
 // nmask[l]: bit (n - 4) set iff an overflow entry of locus l has alt+ref == n, 4 <= n <= OV_NE (static)
 __global__ __launch_bounds__(256) void k_ovf_nmask(uint64_t L, const uint64_t *__restrict__ ovc_ptr,
                                                    const uint64_t *__restrict__ ovc_ent, uint32_t *__restrict__ nmask)
@@ -1039,6 +1075,7 @@ __device__ __forceinline__ T group16_sum(T v)
     for (int m = LF_LANES / 2; m > 0; m >>= 1) v += __shfl_xor(v, m, LF_LANES);
     return v;
 }
+template <bool INLINE_OVF>  // the overflow entries' log-pmfs: evaluated here (deep coverage) or read from ovf_lp (k_ovf_values)
 __global__ __launch_bounds__(256) void k_locus_finalize(uint64_t L, int locus_mode, uint64_t nloc, uint32_t n_sub,
                                                         const uint32_t *__restrict__ n_min_p,
                                                         const uint32_t *__restrict__ hist_min,
@@ -1048,6 +1085,7 @@ __global__ __launch_bounds__(256) void k_locus_finalize(uint64_t L, int locus_mo
                                                         const uint8_t *__restrict__ mask,
                                                         const uint64_t *__restrict__ ovc_ptr /*null: no overflow*/,
                                                         const uint64_t *__restrict__ ovc_ent,
+                                                        const double *__restrict__ ovf_lp /*null: evaluate here*/,
                                                         const double *__restrict__ otab, const double *__restrict__ lf,
                                                         const double2 *__restrict__ ab, double *__restrict__ out)
 {
@@ -1094,16 +1132,19 @@ __global__ __launch_bounds__(256) void k_locus_finalize(uint64_t L, int locus_mo
         for (int u = 0; u < 4; u++) {
             const uint64_t i = i0 + (uint64_t)u * LF_LANES;
             en[u] = i < oend ? ovc_ent[i] : ~0ull;
+            lp[u] = (!INLINE_OVF && i < oend) ? ovf_lp[i] : 0.0;  // (stored by k_ovf_values: zero at masked loci)
         }
 #pragma unroll
         for (int u = 0; u < 4; u++) w[u] = en[u] != ~0ull ? flag_bits[ENT_IDX(en[u]) >> 5] : 0u;
 #pragma unroll
         for (int u = 0; u < 4; u++) {
+            if (!INLINE_OVF) break;
             lp[u] = 0.0;
             if (en[u] == ~0ull || !live) continue;  // (a masked locus has no PMFData, main.rs:556: only its tallies count)
             const uint32_t a = ENT_ALT(en[u]), r = ENT_REF(en[u]), n = a + r;
             if (n == 0) lp[u] = 0.0;  // quirk Q14: exactly zero
-            else if (n < (uint32_t)OV_NT) lp[u] = dm_ln_choose(lf, a, r) + (orow[a] + orow[OV_NT + r] - orow[2 * OV_NT + n]);
+            else if (n < (uint32_t)OV_NT)  // (totals below 18: ln C straight out of the factorial table — no ln_gamma branch inlined here)
+                lp[u] = (lf[n] - lf[a] - lf[r]) + (orow[a] + orow[OV_NT + r] - orow[2 * OV_NT + n]);
             else {
                 const double2 p = ab[l];
                 lp[u] = ov_slow_log_pmf(lf, p.x, p.y, a, r);
@@ -1404,7 +1445,7 @@ void tiled_free(cellector_ctx *c)
     dev_free(c->c4_ptr); dev_free(c->c4_ent); dev_free(c->ovc_ptr); dev_free(c->ovc_ent);
     dev_free(c->hist_all); dev_free(c->tab); dev_free(c->part); dev_free(c->ab3);
     dev_free(c->masked_cnt); dev_free(c->flag_bits); dev_free(c->ovf_tab); dev_free(c->ovf_etab);
-    dev_free(c->ovf_sum); dev_free(c->ovf_tier_row[0]); dev_free(c->ovf_tier_row[1]); dev_free(c->ovf_tier_ent[0]); dev_free(c->ovf_tier_ent[1]); dev_free(c->ovf_ell_ptr); dev_free(c->ovf_ell); dev_free(c->ovf_nmask); dev_free(c->tile_work); dev_free(c->minlist); dev_free(c->hist_min); dev_free(c->roff); dev_free(c->c4r); dev_free(c->mroff); dev_free(c->mbeg);
+    dev_free(c->ovf_sum); dev_free(c->ovf_lp); dev_free(c->ovc_locus); dev_free(c->ovf_tier_row[0]); dev_free(c->ovf_tier_row[1]); dev_free(c->ovf_tier_ent[0]); dev_free(c->ovf_tier_ent[1]); dev_free(c->ovf_ell_ptr); dev_free(c->ovf_ell); dev_free(c->ovf_nmask); dev_free(c->tile_work); dev_free(c->minlist); dev_free(c->hist_min); dev_free(c->roff); dev_free(c->c4r); dev_free(c->mroff); dev_free(c->mbeg);
     c->mroff_cap = 0;
     c->tiled_ready = false;
     c->ovf_n = 0; c->n_masked_loci = 0;
@@ -1539,6 +1580,8 @@ cellector_status tiled_build(cellector_ctx *c)
     if (c->ovf_n >= (1ull << 32)) return ctx_fail(c, CELLECTOR_EINVAL, "tiled engine: more than 2^32 overflow entries per shard");
     CHK(dev_alloc(c, &c->ovf_sum, 3 * 2 * nloc));
     CHK(dev_alloc(c, &c->ovf_tab, L * OV_ROW));
+    CHK(dev_alloc(c, &c->ovf_lp, c->ovf_n));
+    CHK(dev_alloc(c, &c->ovc_locus, c->ovf_n));
     CHK(dev_alloc(c, &c->ovf_etab, L * OV_REC));
     CHK(dev_alloc(c, &c->ovf_nmask, L));
     {
@@ -1581,6 +1624,8 @@ cellector_status tiled_build(cellector_ctx *c)
         dev_free(cnt0); dev_free(cnt1);
         CHK(st);
     }
+    if (L && c->ovf_n)
+        hipLaunchKernelGGL(k_ovf_locus_ids, dim3(gcap(L, 4)), dim3(256), 0, c->stream, L, c->ovc_ptr, c->ovc_locus);
     if (L && c->ovf_n)
         hipLaunchKernelGGL(k_ovf_nmask, dim3(gcap(L, 4)), dim3(256), 0, c->stream, L, c->ovc_ptr, c->ovc_ent, c->ovf_nmask);
     HIPCHK(c, hipGetLastError());
@@ -1676,6 +1721,9 @@ static void launch_overflow_cell(cellector_ctx *c, hipStream_t st, const double2
 static void launch_overflow_locus_values(cellector_ctx *c, hipStream_t st, const double2 *ab)
 {
     hipLaunchKernelGGL(k_ovf_tables, dim3(gcap(c->L * 3, 256, 0x7fffffffu)), dim3(256), 0, st, c->L, ab, c->ovf_nmask, c->ovf_tab);
+    if (!c->ovf_deep)  // shallow coverage: the values are stored here, beside the tile kernel, and the finalize reads them
+        hipLaunchKernelGGL(k_ovf_values, dim3(gcap(c->ovf_n, 256, 0x7fffffffu)), dim3(256), 0, st, c->ovf_n, c->ovc_locus, c->ovc_ent, ab,
+                           c->lf, c->ovf_tab, c->ovf_lp);
 }
 
 static bool have_overflow(const cellector_ctx *c) { return c->ovf_n != 0 && c->L != 0 && c->nloc != 0; }
@@ -1876,10 +1924,13 @@ cellector_status tiled_locus_pass(cellector_ctx *c)
         HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join2, 0));
         c->ovf_locus_pending = false;
     }
-    hipLaunchKernelGGL(k_locus_finalize, dim3(gcap(c->L * LF_LANES, 256, 0x7fffffffu)), dim3(256), 0, c->stream, c->L, c->locus_mode,
-                       c->nloc, c->lr_sub, c->d_counters + DC_N_MIN, c->hist_min, c->flag_bits, c->hist_all, c->tab_em,
-                       (uint32_t)c->tab_em_stride, c->mask, c->ovf_n ? c->ovc_ptr : (const uint64_t *)nullptr, c->ovc_ent,
-                       c->ovf_tab, c->lf, c->ab, c->x_locus);
+#define LAUNCH_LF(INL)                                                                                                             \
+    hipLaunchKernelGGL(k_locus_finalize<INL>, dim3(gcap(c->L * LF_LANES, 256, 0x7fffffffu)), dim3(256), 0, c->stream, c->L, c->locus_mode, \
+                       c->nloc, c->lr_sub, c->d_counters + DC_N_MIN, c->hist_min, c->flag_bits, c->hist_all, c->tab_em,            \
+                       (uint32_t)c->tab_em_stride, c->mask, c->ovf_n ? c->ovc_ptr : (const uint64_t *)nullptr, c->ovc_ent, c->ovf_lp, \
+                       c->ovf_tab, c->lf, c->ab, c->x_locus)
+    if (c->ovf_deep) LAUNCH_LF(true); else LAUNCH_LF(false);
+#undef LAUNCH_LF
     timer_end(c, CELLECTOR_K_LOCUS_STATS);
     HIPCHK(c, hipGetLastError());
     return CELLECTOR_OK;
