@@ -328,6 +328,7 @@ cellector_status cellector_set_option(cellector_ctx *c, const char *key, int64_t
         c->overlap = (int)v;
     }
     else if (!strcmp(key, "side_lds")) c->side_lds = (int)v;
+    else if (!strcmp(key, "ovf_deep_wide")) c->ovf_deep_wide = v != 0;
     else if (!strcmp(key, "ovf_deep")) {
         if (v < -1 || v > 1) return ctx_fail(c, CELLECTOR_EINVAL, "ovf_deep must be -1 (automatic), 0 or 1");
         c->ovf_deep_opt = (int)v;

@@ -126,6 +126,7 @@ struct cellector_ctx {
     int side_lds = -1;               // option "side_lds": dynamic LDS bytes requested by the cell-side overflow kernel (residency
                                      // throttle; -1 = automatic)
     int ovf_deep_opt = -1;           // option "ovf_deep": -1 = decided per matrix (tiled_build), 0 / 1 = forced
+    bool ovf_deep_wide = true;       // option "ovf_deep_wide": deep form with 16 lanes per row (0: a thread per row; A/B)
     bool ovf_deep = false;           // the overflow entries are a large share of the matrix (deep coverage): their cell side runs
                                      // the full form of the direct kernel (totals up to 17 in one kernel), never throttled
     bool ovf_locus_pending = false;  // the side stream still owes this iteration's locus-side overflow tables / values (event ev_join2)

@@ -373,6 +373,14 @@ __global__ __launch_bounds__(T_THREADS, 4) void k_tile_ll(uint32_t nb, uint32_t 
 //               the locus (the lanes of a locus share its table row).  Only the EM pass needs the tables, and only at the
 //               locus finalize: the table kernel follows the cell side on the side stream.
 // ---------------------------------------------------------------------------------------------------------
+#define LF_LANES 16  // lanes that share a locus (k_locus_finalize) or a row (k_ovf_cell_wide)
+template <typename T>
+__device__ __forceinline__ T group16_sum(T v)
+{
+#pragma unroll
+    for (int m = LF_LANES / 2; m > 0; m >>= 1) v += __shfl_xor(v, m, LF_LANES);
+    return v;
+}
 #define OV_NT 18  // cumulative tables cover counts 0..17; larger counts take the generic device_math path
 #define OV_NE 17  // expected terms E(n) tabulated for n = 4..17
 #define OV_FAST_N DM_CHUNK  // the cell side's fast kernel takes totals up to this (99 % of the overflow entries)
@@ -579,6 +587,67 @@ __global__ __launch_bounds__(256) void k_ovf_cell_direct(
     }
     o_ll[row] = s;
     if (EXPECTED) o_ell[row] = e;
+}
+
+// Deep coverage (ovf_deep): hundreds of overflow entries per row.  A thread per row walking them one after the other left the
+// chip waiting (7.5 ms at 1M x 200k with 13 % overflow entries).  Here 16 lanes share a row: lane j takes the row's entries
+// j, j + 16, ... straight out of the overflow CSR (a 128-byte line per 16 lanes), 16 gathers of a row in flight at once, and
+// every total up to OV_NE = 17 takes the SAME instruction path — one product loop, one reciprocal, one log: a ratio of two
+// products of at most 17 factors stays far inside the f64 range for alpha + beta below 1e17, so no chunking — because a wave
+// whose lanes split between a short-total and a long-total path pays for both.  alpha, beta and E(5..8) come out of ONE
+// 64-byte record per locus in the EM pass.  The per-lane sums are added by a fixed-shape butterfly (deterministic).
+// (Measured and dropped: one launch per locus range whose records fit an L2 — 9.3 -> 11-14 ms: the kernel is bound by its
+// arithmetic, not by the gathers.)
+template <bool EXPECTED>
+__global__ __launch_bounds__(256) void k_ovf_cell_wide(uint64_t n_rows, const uint64_t *__restrict__ ovf_ptr,
+                                                       const uint64_t *__restrict__ ovf_ent, const double2 *__restrict__ ab,
+                                                       const double *__restrict__ lf, const double *__restrict__ etab,
+                                                       const double *__restrict__ otab, double *__restrict__ o_ll,
+                                                       double *__restrict__ o_ell)
+{
+    const uint32_t j = threadIdx.x % LF_LANES;
+    const uint64_t row_raw = ((uint64_t)blockIdx.x * 256 + threadIdx.x) / LF_LANES;
+    const bool in = row_raw < n_rows;
+    const uint64_t row = in ? row_raw : n_rows - 1;  // whole waves stay in the butterflies
+    const uint64_t beg = ovf_ptr[row], end = in ? ovf_ptr[row + 1] : beg;
+    double s = 0.0, e = 0.0;
+#pragma unroll 2
+    for (uint64_t i = beg + j; i < end; i += LF_LANES) {
+        const uint64_t en = ovf_ent[i];
+        const uint32_t l = ENT_IDX(en), a = ENT_ALT(en), r = ENT_REF(en), n = a + r;
+        const double *rec = etab + (uint64_t)l * OV_REC;
+        const double2 p = EXPECTED ? *reinterpret_cast<const double2 *>(rec) : ab[l];
+        double ev = 0.0;
+        if (EXPECTED) {
+            if (n > (uint32_t)T_K && n <= (uint32_t)OV_FAST_N) ev = rec[n - 3];
+            else if (n > (uint32_t)OV_FAST_N && n <= (uint32_t)OV_NE) ev = otab[(uint64_t)l * OV_ROW + OV_EOFF + (n - 4)];
+        }
+        // masked locus: no PMFData (main.rs:556); 0/0 entry: exactly zero (Q14); totals above OV_NE: the generic list
+        if (!(p.x >= 0.0) || n == 0 || n > (uint32_t)OV_NE) continue;
+        double lp;
+        if (p.x + p.y < 1e17) {
+            double num = 1.0, den = 1.0, fa = p.x, fb = p.y, fab = p.x + p.y;
+            for (uint32_t k = 0; k < n; ++k) {
+                const bool isa = k < a;
+                num *= isa ? fa : fb;
+                den *= fab;
+                fa += isa ? 1.0 : 0.0;
+                fb += isa ? 0.0 : 1.0;
+                fab += 1.0;
+            }
+            lp = (lf[n] - lf[a] - lf[r]) + log(num * ov_rcp(den));
+        } else {
+            lp = ov_slow_log_pmf(lf, p.x, p.y, a, r);
+        }
+        s += lp;
+        if (EXPECTED) e += ev;
+    }
+    s = group16_sum(s);
+    if (EXPECTED) e = group16_sum(e);
+    if (in && j == 0) {
+        o_ll[row] = s;
+        if (EXPECTED) o_ell[row] = e;
+    }
 }
 
 // 64-row ELLPACK copy of the overflow CSR.  COUNT: slots of group g = 64 x its longest row; FILL: lane = row & 63 writes
@@ -1067,14 +1136,6 @@ __global__ __launch_bounds__(LR_THREADS) void k_minority_ranges(int locus_mode, 
 // locus: lane j < 14 takes code j's count (sum of the planes), static histogram and log-pmf; the locus' overflow entries
 // (alt+ref == 0 or > T_K; ~1 %, their log-pmfs evaluated from the locus' cumulative-log row) are walked 16 at a time; per-lane partial results
 // are added by a 4-step butterfly over the 16 lanes (fixed shape: deterministic).
-#define LF_LANES 16
-template <typename T>
-__device__ __forceinline__ T group16_sum(T v)
-{
-#pragma unroll
-    for (int m = LF_LANES / 2; m > 0; m >>= 1) v += __shfl_xor(v, m, LF_LANES);
-    return v;
-}
 template <bool INLINE_OVF>  // the overflow entries' log-pmfs: evaluated here (deep coverage) or read from ovf_lp (k_ovf_values)
 __global__ __launch_bounds__(256) void k_locus_finalize(uint64_t L, int locus_mode, uint64_t nloc, uint32_t n_sub,
                                                         const uint32_t *__restrict__ n_min_p,
@@ -1687,7 +1748,10 @@ static void launch_overflow_cell(cellector_ctx *c, hipStream_t st, const double2
         // a tile workgroup (one wave per SIMD instead of two).  On a big shard the kernel still ends well inside the tile
         // kernel and disturbs it less (cfg4: 2.83 -> 2.78 ms per iteration); a small shard's tile kernel is too short for that.
         const size_t lds_req = deep ? 0 : c->side_lds >= 0 ? (size_t)c->side_lds : (st == c->side && c->nloc >= (1ull << 19) ? 5000 : 0);
-        if (deep)
+        if (deep && c->ovf_deep_wide)
+            hipLaunchKernelGGL(k_ovf_cell_wide<true>, dim3(gcap(c->nloc * LF_LANES, 256, 0x7fffffffu)), dim3(256), 0, st, c->nloc, c->ovf_ptr,
+                               c->ovf_ent, ab, c->lf, c->ovf_etab, c->ovf_tab, o_ll, o_ell);
+        else if (deep)
             hipLaunchKernelGGL((k_ovf_cell_direct<true, false, true>), dim3(g), dim3(256), 0, st, c->nloc, c->ovf_ell_ptr, c->ovf_ell, ab,
                                c->lf, c->ovf_etab, c->ovf_tab, o_ll, o_ell);
         else if (lds_req)  // one block per CU: the 64-VGPR form with the packed per-locus record
@@ -1703,7 +1767,10 @@ static void launch_overflow_cell(cellector_ctx *c, hipStream_t st, const double2
             hipLaunchKernelGGL((k_ovf_cell_listed<true, true>), dim3(gcap(c->ovf_n_tier[1], 256, 0x7fffffffu)), dim3(256), 0, st,
                                c->ovf_n_tier[1], c->ovf_tier_row[1], c->ovf_tier_ent[1], ab, c->lf, c->ovf_tab, o_ll, o_ell);
     } else {
-        if (deep)
+        if (deep && c->ovf_deep_wide)
+            hipLaunchKernelGGL(k_ovf_cell_wide<false>, dim3(gcap(c->nloc * LF_LANES, 256, 0x7fffffffu)), dim3(256), 0, st, c->nloc, c->ovf_ptr,
+                               c->ovf_ent, ab, c->lf, c->ovf_etab, c->ovf_tab, o_ll, o_ell);
+        else if (deep)
             hipLaunchKernelGGL((k_ovf_cell_direct<false, false, true>), dim3(g), dim3(256), 0, st, c->nloc, c->ovf_ell_ptr, c->ovf_ell, ab, c->lf,
                                c->ovf_etab, c->ovf_tab, o_ll, o_ell);
         else

@@ -90,7 +90,8 @@ cellector_status cellector_set_stream(cellector_ctx *ctx, void *hip_stream);
  * "side_lds" (engine 2, default -1: automatic residency throttle of the side-stream kernels),
  * "ovf_deep" (engine 2, default -1: per matrix — when more than 3 % of the entries have alt+ref = 0 or > 4 (deep coverage)
  * their per-cell sums come from ONE unthrottled kernel that takes totals up to 17; 0 / 1 force either form; results agree
- * within rounding: the summation order inside a cell's overflow entries differs),
+ * within rounding: the summation order inside a cell's overflow entries differs; "ovf_deep_wide", default 1: that kernel
+ * gives 16 lanes to a row, 0 = a thread per row — A/B),
  * "tile_groups" (engine 2, default 0: the number of locus-chunk groups of the tile kernel is chosen per matrix;
  * a multiple of 8 up to 64 forces it — set before ingest; results may differ in the last bit),
  * "parse_window" (default 0: a text file of 1 GB or more is uploaded and tokenised in 256 MB windows, a smaller

@@ -221,11 +221,13 @@ def test_overflow_side_stream_equals_in_stream(mods):
     # the residency throttle a big shard gets (which also selects the packed-record form of the cell-side kernel)
     # ... and, last, the form a matrix with this many such entries gets by itself (ovf_deep: one unthrottled kernel for
     # totals up to 17): same values within rounding — the summation order inside a row's overflow entries differs
-    for ov, lds, deep in ((1, -1, 0), (0, -1, 0), (2, -1, 0), (1, 5000, 0), (1, -1, -1), (0, -1, 1)):
+    # (the deep form has two kernels: 16 lanes per row — the default — and a thread per row)
+    for ov, lds, deep, wide in ((1, -1, 0, 1), (0, -1, 0, 1), (2, -1, 0, 1), (1, 5000, 0, 1), (1, -1, -1, 1), (0, -1, 1, 1), (1, -1, 1, 0)):
         g = mods["Cellector"](0)
         g.set_option("overlap", ov)
         g.set_option("side_lds", lds)
         g.set_option("ovf_deep", deep)
+        g.set_option("ovf_deep_wide", wide)
         g.load_coo(L, N, lo, ce, al, re)
         o = mods["ob"].Oracle.from_coo(L, N, lo, ce, al, re)
         run = []
