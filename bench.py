@@ -242,6 +242,16 @@ def main():
     allreduce(el, dist.ReduceOp.MAX)
     elapsed = float(el.item())
     ms_per_step = elapsed / args.steps * 1e3
+    # every rank ran the same exact selection on the same all-gathered keys and saw the same all-reduced counters: the
+    # iteration summaries must agree to the bit (checked, reported in the line)
+    ranks_agree = True
+    if world > 1:
+        mine = torch.tensor([last.threshold, last.median, last.iqr, float(last.n_excluded), float(last.any_change)],
+                            dtype=torch.float64, device=dev)
+        lo, hi = mine.clone(), mine.clone()
+        allreduce(lo, dist.ReduceOp.MIN)
+        allreduce(hi, dist.ReduceOp.MAX)
+        ranks_agree = bool(torch.equal(lo, hi))
 
     # ---- the dominant kernel's duration: HIP events on the launch stream, recorded inside the timed region
     dom_id = ffi.K_TILE_LL if args.engine == 2 else ffi.K_CELL_LL
@@ -342,7 +352,7 @@ def main():
                        "nnz_overflow": int(info.nnz_overflow), "tile_bytes": int(info.tile_bytes)},
             "setup_s": t_setup,
             "last_iteration": {"n_excluded": int(last.n_excluded), "threshold": last.threshold,
-                               "any_change": int(last.any_change)},
+                               "any_change": int(last.any_change), "ranks_agree": ranks_agree},
         }
 
     # ---- CPU baseline: the oracle (port of the reference's single-threaded path) on a bounded cell sample
