@@ -460,7 +460,7 @@ cellector_status cellector_ingest_mtx(cellector_ctx *c, const char *alt_path, co
 }  // extern "C"
 
 // Multi-device text ingest, step 1: shard `c` tokenises the whole pair and stages the entries of ALL cells (global cell index).
-cellector_status ffi_stage_mtx_all_cells(cellector_ctx *c, const char *alt_path, const char *ref_path)
+cellector_status ffi_stage_mtx_all_cells(cellector_ctx *c, const char *alt_path, const char *ref_path, cellector_ctx *helper)
 {
     REQUIRE(c, alt_path && ref_path, "null path");
     MtxInput *in = nullptr;
@@ -468,7 +468,7 @@ cellector_status ffi_stage_mtx_all_cells(cellector_ctx *c, const char *alt_path,
     CHK(mtx_input_open(c, alt_path, ref_path, &in, &tl, &tc));
     c->ingest_all_cells = true;
     cellector_status s = begin_ingest(c, tl, tc);
-    if (s == CELLECTOR_OK) s = ingest_stage_mtx_device(c, in);
+    if (s == CELLECTOR_OK) s = ingest_stage_mtx_device(c, in, helper);
     c->ingest_all_cells = false;
     mtx_input_close(in);
     return s;

@@ -257,7 +257,7 @@ cellector_status ingest_pass1(cellector_ctx *c);
 cellector_status ingest_split_coo(cellector_ctx *src, uint64_t cb, uint64_t ce, uint64_t *keep, uint32_t **o_locus, uint32_t **o_cell,
                                   uint16_t **o_alt, uint16_t **o_ref, uint64_t *n_out);
 // multi-device text ingest (cellector_ffi.cpp): stage the whole pair on one shard / hand a shard its routed entries
-cellector_status ffi_stage_mtx_all_cells(cellector_ctx *c, const char *alt_path, const char *ref_path);
+cellector_status ffi_stage_mtx_all_cells(cellector_ctx *c, const char *alt_path, const char *ref_path, cellector_ctx *helper);
 cellector_status ffi_adopt_staged(cellector_ctx *c, uint64_t total_loci, uint64_t total_cells, uint32_t *locus, uint32_t *cell,
                                   uint16_t *alt, uint16_t *ref, uint64_t n, bool sorted);
 cellector_status ingest_build(cellector_ctx *c, uint64_t min_alt, uint64_t min_ref);
@@ -281,4 +281,4 @@ struct MtxInput;
 cellector_status mtx_input_open(const cellector_ctx *c, const char *alt_path, const char *ref_path, MtxInput **out,
                                 uint64_t *total_loci, uint64_t *total_cells);
 void mtx_input_close(MtxInput *in);
-cellector_status ingest_stage_mtx_device(cellector_ctx *c, MtxInput *in);
+cellector_status ingest_stage_mtx_device(cellector_ctx *c, MtxInput *in, cellector_ctx *helper = nullptr /*parses the ref file*/);

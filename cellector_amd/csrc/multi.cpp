@@ -173,7 +173,8 @@ cellector_status multi_set_option(cellector_ctx *root, const char *key, int64_t 
 
 // ---- ingest ------------------------------------------------------------------------------------------------------------------
 // (every shard sets its own canonical cell range in begin_ingest: a shard with a communicator ignores cellector_set_shard)
-// The text pair is read, uploaded and tokenised ONCE, on shard 0's device; its entries are then cut by owning cell range
+// The text pair is read, uploaded and tokenised ONCE — the alt file on shard 0's device, the ref file on shard 1's at the same
+// time (the two are independent byte streams until they are zipped line by line); its entries are then cut by owning cell range
 // (file order kept) and every piece goes to its shard's device (peer copy over xGMI; a plain device copy between logical
 // shards of one GPU).  n shards each parsing the whole pair would read the text n times on the host and push it over n PCIe
 // links at once: slower than one GPU from a few shards on.  (Parsing 1/n of the bytes per GPU is the scalable form — it
@@ -189,7 +190,13 @@ cellector_status multi_ingest_mtx(cellector_ctx *root, const char *alt_path, con
         return st;
     };
     if (hipSetDevice(s0->device) != hipSuccess) return ctx_fail(root, CELLECTOR_EDEVICE, "hipSetDevice failed");
-    cellector_status st = ffi_stage_mtx_all_cells(s0, alt_path, ref_path);
+    // (a second shard tokenises the ref file meanwhile: on another GPU that is a second PCIe link and a second parser)
+    // (logical shards of ONE GPU gain nothing from it — two parsers then share one link: 0.59 s against 0.26 s for 5.7 GB —
+    //  so only a shard on another device helps; CELLECTOR_MULTI_REF_HELPER=1 forces it: tests of that path on a one-GPU box)
+    cellector_ctx *helper = nullptr;
+    for (size_t r = 1; r < m->shards.size() && !helper; r++)
+        if (m->shards[r]->device != s0->device || getenv("CELLECTOR_MULTI_REF_HELPER")) helper = m->shards[r];
+    cellector_status st = ffi_stage_mtx_all_cells(s0, alt_path, ref_path, helper);
     if (st != CELLECTOR_OK) return fail(s0, st);
     // detach the all-cells arrays from shard 0 (its own piece is cut from them like the others')
     cellector_ctx all;  // (a plain holder: no device state of its own is created or destroyed)

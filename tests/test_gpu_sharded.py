@@ -51,7 +51,14 @@ def test_multi_device_ctx_equals_single_ctx_and_oracle(devices, oracle_lib, hip_
         if source == "coo":
             m.load_coo(L, N, *coo)
         else:
-            m.load_mtx(a_path, r_path)
+            # the text is tokenised once and its entries routed to the shards; with GPUs to spare the ref file is tokenised
+            # on a second one meanwhile — forced here so that a one-GPU box runs that path too (5-shard case)
+            if len(devices) > 2:
+                os.environ["CELLECTOR_MULTI_REF_HELPER"] = "1"
+            try:
+                m.load_mtx(a_path, r_path)
+            finally:
+                os.environ.pop("CELLECTOR_MULTI_REF_HELPER", None)
         o = oracle_lib.Oracle.from_coo(L, N, *coo)
         T._check_matrix(m, o)                      # dims, locus ids/counts, entries per cell, CSR rows across the shards
         dm = m.dims()
