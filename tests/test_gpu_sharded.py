@@ -55,6 +55,7 @@ def test_multi_device_ctx_equals_single_ctx_and_oracle(devices, oracle_lib, hip_
             # on a second one meanwhile — forced here so that a one-GPU box runs that path too (5-shard case)
             if len(devices) > 2:
                 os.environ["CELLECTOR_MULTI_REF_HELPER"] = "1"
+                m.set_option("parse_window", 4096)  # ... through the windowed parser (files of 1 GB and more take it)
             try:
                 m.load_mtx(a_path, r_path)
             finally:
