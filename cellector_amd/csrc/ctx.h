@@ -137,6 +137,7 @@ struct cellector_ctx {
     uint32_t *ovf_tier_row[2] = {nullptr, nullptr};  // the overflow entries with alt+ref in 9..17 (tier 0) / above (tier 1):
     uint64_t *ovf_tier_ent[2] = {nullptr, nullptr};  //   their rows and packed entries, in row order
     uint64_t ovf_n_tier[2] = {0, 0};
+    double *ovf_tier_val = nullptr;  // [2][ovf_n_tier[1]] per pass: log-pmf / expected term of the tier-1 entries (k_ovf_listed_values)
     uint32_t *ovf_nmask = nullptr;   // [L] which alt+ref totals (4..17) occur among the locus' overflow entries
     uint64_t *c4_ptr = nullptr;      // [L+1] compact CSC of regular entries
     uint32_t *c4_ent = nullptr;      // 32-bit entries cell_local | code << 28, or 24-bit cell | code << 20 (c4_bits)

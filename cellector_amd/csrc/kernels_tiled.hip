@@ -738,6 +738,61 @@ __global__ __launch_bounds__(256) void k_ovf_cell_listed(uint64_t n_list, const 
     if (EXPECTED) o_ell[row] += e;
 }
 
+// Totals above OV_NE (tier 1: a few entries in 10^4 even with deep coverage) take the generic arithmetic — chunked products,
+// and for the expected term the reference's log-space fold over all n + 1 pmfs: O(n^2) for one thread, and a wave waits for its
+// longest total (0.40 ms at 200k x 100k deep: more than the kernel of all other overflow entries).  Here 16 lanes share a listed
+// entry: lane j folds the terms k = j, j + 16, ... left to right, the 16 partial results meet in a fixed-shape butterfly
+// (logsumexp is commutative: every lane ends with the same bits; the association differs from the reference's single left fold
+// by rounding only).  The values go to two small arrays; k_ovf_listed_add walks each row's run and adds them in list order.
+template <bool EXPECTED>
+__global__ __launch_bounds__(256) void k_ovf_listed_values(uint64_t n_list, const uint64_t *__restrict__ ents,
+                                                           const double2 *__restrict__ ab, const double *__restrict__ lf,
+                                                           double *__restrict__ v_lp, double *__restrict__ v_e)
+{
+    const uint32_t j = threadIdx.x % LF_LANES;
+    const uint64_t idx = ((uint64_t)blockIdx.x * 256 + threadIdx.x) / LF_LANES;
+    const bool in = idx < n_list;
+    const uint64_t i = in ? idx : n_list - 1;  // whole waves stay in the butterfly
+    const uint64_t en = ents[i];
+    const uint32_t l = ENT_IDX(en), a = ENT_ALT(en), r = ENT_REF(en), n = a + r;
+    const double2 p = ab[l];
+    const bool live = p.x >= 0.0;  // else a masked locus: no PMFData (main.rs:556)
+    double lp = 0.0, e = 0.0;
+    if (live && j == 0) lp = dm_log_bb_pmf(lf, p.x, p.y, a, r);
+    if (EXPECTED && live) {
+        // (n > OV_NE >= LF_LANES: every lane has at least the term k = j)
+        e = 2.0 * dm_log_bb_pmf(lf, p.x, p.y, j, n - j);
+        for (uint32_t k = j + LF_LANES; k <= n; k += LF_LANES) e = dm_logsumexp(e, 2.0 * dm_log_bb_pmf(lf, p.x, p.y, k, n - k));
+    }
+    if (EXPECTED) {
+#pragma unroll
+        for (int m = LF_LANES / 2; m > 0; m >>= 1) {
+            const double o = __shfl_xor(e, m, LF_LANES);
+            if (live) e = dm_logsumexp(e, o);
+        }
+    }
+    if (in && j == 0) {
+        v_lp[i] = lp;
+        if (EXPECTED) v_e[i] = live ? e : 0.0;
+    }
+}
+template <bool EXPECTED>
+__global__ __launch_bounds__(256) void k_ovf_listed_add(uint64_t n_list, const uint32_t *__restrict__ rows, const double *__restrict__ v_lp,
+                                                        const double *__restrict__ v_e, double *__restrict__ o_ll, double *__restrict__ o_ell)
+{
+    const uint64_t i0 = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i0 >= n_list) return;
+    const uint32_t row = rows[i0];
+    if (i0 > 0 && rows[i0 - 1] == row) return;
+    double s = 0.0, e = 0.0;
+    for (uint64_t i = i0; i < n_list && rows[i] == row; i++) {
+        s += v_lp[i];
+        if (EXPECTED) e += v_e[i];
+    }
+    o_ll[row] += s;
+    if (EXPECTED) o_ell[row] += e;
+}
+
 // chunk-group partials in group order, then the row's overflow sum, then the normalisation (main.rs:314-323).
 // Two rows per thread: 16-byte loads and stores (8-byte ones left this 190 MB stream at 1.8 TB/s).
 template <bool EXPECTED>
@@ -1506,7 +1561,7 @@ void tiled_free(cellector_ctx *c)
     dev_free(c->c4_ptr); dev_free(c->c4_ent); dev_free(c->ovc_ptr); dev_free(c->ovc_ent);
     dev_free(c->hist_all); dev_free(c->tab); dev_free(c->part); dev_free(c->ab3);
     dev_free(c->masked_cnt); dev_free(c->flag_bits); dev_free(c->ovf_tab); dev_free(c->ovf_etab);
-    dev_free(c->ovf_sum); dev_free(c->ovf_lp); dev_free(c->ovc_locus); dev_free(c->ovf_tier_row[0]); dev_free(c->ovf_tier_row[1]); dev_free(c->ovf_tier_ent[0]); dev_free(c->ovf_tier_ent[1]); dev_free(c->ovf_ell_ptr); dev_free(c->ovf_ell); dev_free(c->ovf_nmask); dev_free(c->tile_work); dev_free(c->minlist); dev_free(c->hist_min); dev_free(c->roff); dev_free(c->c4r); dev_free(c->mroff); dev_free(c->mbeg);
+    dev_free(c->ovf_sum); dev_free(c->ovf_lp); dev_free(c->ovc_locus); dev_free(c->ovf_tier_row[0]); dev_free(c->ovf_tier_row[1]); dev_free(c->ovf_tier_ent[0]); dev_free(c->ovf_tier_ent[1]); dev_free(c->ovf_tier_val); dev_free(c->ovf_ell_ptr); dev_free(c->ovf_ell); dev_free(c->ovf_nmask); dev_free(c->tile_work); dev_free(c->minlist); dev_free(c->hist_min); dev_free(c->roff); dev_free(c->c4r); dev_free(c->mroff); dev_free(c->mbeg);
     c->mroff_cap = 0;
     c->tiled_ready = false;
     c->ovf_n = 0; c->n_masked_loci = 0;
@@ -1684,6 +1739,7 @@ cellector_status tiled_build(cellector_ctx *c)
         }
         dev_free(cnt0); dev_free(cnt1);
         CHK(st);
+        CHK(dev_alloc(c, &c->ovf_tier_val, 2 * c->ovf_n_tier[1]));  // (log-pmf, expected term) of the tier-1 entries, per pass
     }
     if (L && c->ovf_n)
         hipLaunchKernelGGL(k_ovf_locus_ids, dim3(gcap(L, 4)), dim3(256), 0, c->stream, L, c->ovc_ptr, c->ovc_locus);
@@ -1763,9 +1819,12 @@ static void launch_overflow_cell(cellector_ctx *c, hipStream_t st, const double2
         if (c->ovf_n_tier[0] && !deep)
             hipLaunchKernelGGL((k_ovf_cell_listed<true, false>), dim3(gcap(c->ovf_n_tier[0], 256, 0x7fffffffu)), dim3(256), 0, st,
                                c->ovf_n_tier[0], c->ovf_tier_row[0], c->ovf_tier_ent[0], ab, c->lf, c->ovf_tab, o_ll, o_ell);
-        if (c->ovf_n_tier[1])
-            hipLaunchKernelGGL((k_ovf_cell_listed<true, true>), dim3(gcap(c->ovf_n_tier[1], 256, 0x7fffffffu)), dim3(256), 0, st,
-                               c->ovf_n_tier[1], c->ovf_tier_row[1], c->ovf_tier_ent[1], ab, c->lf, c->ovf_tab, o_ll, o_ell);
+        if (c->ovf_n_tier[1]) {
+            hipLaunchKernelGGL(k_ovf_listed_values<true>, dim3(gcap(c->ovf_n_tier[1] * LF_LANES, 256, 0x7fffffffu)), dim3(256), 0, st,
+                               c->ovf_n_tier[1], c->ovf_tier_ent[1], ab, c->lf, c->ovf_tier_val, c->ovf_tier_val + c->ovf_n_tier[1]);
+            hipLaunchKernelGGL(k_ovf_listed_add<true>, dim3(gcap(c->ovf_n_tier[1], 256, 0x7fffffffu)), dim3(256), 0, st, c->ovf_n_tier[1],
+                               c->ovf_tier_row[1], c->ovf_tier_val, c->ovf_tier_val + c->ovf_n_tier[1], o_ll, o_ell);
+        }
     } else {
         if (deep && c->ovf_deep_wide)
             hipLaunchKernelGGL(k_ovf_cell_wide<false>, dim3(gcap(c->nloc * LF_LANES, 256, 0x7fffffffu)), dim3(256), 0, st, c->nloc, c->ovf_ptr,
@@ -1779,9 +1838,12 @@ static void launch_overflow_cell(cellector_ctx *c, hipStream_t st, const double2
         if (c->ovf_n_tier[0] && !deep)
             hipLaunchKernelGGL((k_ovf_cell_listed<false, false>), dim3(gcap(c->ovf_n_tier[0], 256, 0x7fffffffu)), dim3(256), 0, st,
                                c->ovf_n_tier[0], c->ovf_tier_row[0], c->ovf_tier_ent[0], ab, c->lf, c->ovf_tab, o_ll, o_ell);
-        if (c->ovf_n_tier[1])
-            hipLaunchKernelGGL((k_ovf_cell_listed<false, true>), dim3(gcap(c->ovf_n_tier[1], 256, 0x7fffffffu)), dim3(256), 0, st,
-                               c->ovf_n_tier[1], c->ovf_tier_row[1], c->ovf_tier_ent[1], ab, c->lf, c->ovf_tab, o_ll, o_ell);
+        if (c->ovf_n_tier[1]) {
+            hipLaunchKernelGGL(k_ovf_listed_values<false>, dim3(gcap(c->ovf_n_tier[1] * LF_LANES, 256, 0x7fffffffu)), dim3(256), 0, st,
+                               c->ovf_n_tier[1], c->ovf_tier_ent[1], ab, c->lf, c->ovf_tier_val, c->ovf_tier_val + c->ovf_n_tier[1]);
+            hipLaunchKernelGGL(k_ovf_listed_add<false>, dim3(gcap(c->ovf_n_tier[1], 256, 0x7fffffffu)), dim3(256), 0, st, c->ovf_n_tier[1],
+                               c->ovf_tier_row[1], c->ovf_tier_val, c->ovf_tier_val + c->ovf_n_tier[1], o_ll, o_ell);
+        }
     }
 }
 // locus side: the per-locus cumulative-log tables that k_locus_finalize evaluates the overflow entries' log-pmfs from, on stream `st`
