@@ -1949,9 +1949,10 @@ cellector_status tiled_cell_pass(cellector_ctx *c, const double2 *ab, double *no
     // waits for them (tiled_locus_pass).  (overlap 0: everything in the main stream.)
     if (for_em && c->tables_prebuilt) c->tables_prebuilt = false;  // built ahead by the previous iteration's em_finish
     else CHK(build_tile_tables(c, ab, 0, c->compute_expected, for_em));
-    // (deep coverage: the overflow entries are too many to hide in the tile kernel's spare wave slots — their kernel runs
-    //  with the machine to itself, in the main stream: cfg3-deep 1.93 ms per iteration against 2.32 beside the tile kernel)
-    if (ovf && c->overlap && !c->ovf_deep) {
+    // (deep coverage, ovf_deep: the same arrangement with the unthrottled 16-lanes-per-row kernel — it fills the tile kernel's
+    //  idle issue slots while that runs and has the machine to itself afterwards: 7.8 ms per iteration at 1M x 200k deep
+    //  against 8.3 with the two one after the other)
+    if (ovf && c->overlap) {
         // the tile kernel is launched FIRST: with the tables built ahead the queue is empty when the host gets here, and
         // every launch ahead of it (five on the side stream) would be ~10 us of idle GPU
         CHK(side_fork(c));
@@ -2104,7 +2105,7 @@ cellector_status tiled_posteriors(cellector_ctx *c, double mf0, double lp_min, d
     timer_begin(c, CELLECTOR_K_POSTERIOR);
     const bool ovf = have_overflow(c);
     for (int set = 0; set < 3; set++) CHK(build_tile_tables(c, c->ab3 + (uint64_t)set * L, set, false));
-    if (ovf && c->overlap && !c->ovf_deep) {
+    if (ovf && c->overlap) {
         CHK(side_fork(c));
         for (int set = 0; set < 3; set++) launch_overflow_cell(c, c->side, c->ab3 + (uint64_t)set * L, set, false);
         for (int set = 0; set < 3; set++) CHK(run_tile_pass(c, set, false));
