@@ -163,3 +163,32 @@ def test_oracle_flow_with_locus_filter_and_empty_cells(oracle_lib):
     n_filtered, p = _compare(oracle_lib, L + 1, N, (lo, ce, al, re))
     assert n_filtered >= 1 and not p.mask.all()
     assert (p.entries_per_cell == 0).sum() >= N // 11
+
+
+def test_vcf_genotype_rule_matches_scipy_binomial(oracle_lib):
+    """output_final_vcf's 3-genotype posterior (main.rs:88-118): p = 0.97 * {0.99, 0.5, 0.01} + 0.03 * soup fraction, uniform
+    prior, call at posterior > 0.99 — against scipy.stats.binom"""
+    from scipy.stats import binom
+    rng = np.random.default_rng(5)
+    names = {1: "1/1", 2: "0/1", 3: "0/0", 0: "./."}
+    seen = set()
+    cases = [(0, 0, 0, 0), (30, 0, 0, 40), (5, 5, 100, 3), (0, 1, 1, 0)] + \
+        [tuple(int(x) for x in rng.integers(0, rng.choice([3, 30, 400]), 4)) for _ in range(300)]
+    for amin, rmin, amaj, rmaj in cases:
+        tot_a, tot_r = amin + amaj, rmin + rmaj
+        soup = tot_a / (tot_a + tot_r) if tot_a + tot_r else 0.5
+        ps = [0.97 * g + 0.03 * soup for g in (0.99, 0.5, 0.01)]
+        gmaj, pmaj, gmin, pmin = oracle_lib.vcf_genotype(amin, rmin, amaj, rmaj)
+        for (a, r), g, pmax in (((amaj, rmaj), gmaj, pmaj), ((amin, rmin), gmin, pmin)):
+            lik = np.array([binom.pmf(a, a + r, p) for p in ps])
+            post = lik / 3.0 / (lik / 3.0).sum()
+            assert abs(post.max() - pmax) <= 1e-9 * max(pmax, 1e-300), (amin, rmin, amaj, rmaj)
+            want = 0
+            for code, q in ((1, post[0]), (2, post[1]), (3, post[2])):
+                if q > 0.99:
+                    want = code
+                    break
+            if abs(post.max() - 0.99) > 1e-9:
+                assert g == want, (a, r, post, g)
+            seen.add(names[g])
+    assert seen == {"1/1", "0/1", "0/0", "./."}
