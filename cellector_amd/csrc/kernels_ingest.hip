@@ -188,16 +188,14 @@ __global__ void k_compact(uint64_t TL, const double *__restrict__ p1, double min
     }
 }
 
-// local entry counts: per cell (used loci only) and per total locus (all entries; gives file rank in locus)
-__global__ __launch_bounds__(IB) void k_count(uint64_t n, const uint32_t *__restrict__ locus,
-                                              const uint32_t *__restrict__ cell, const uint64_t *__restrict__ to_used,
-                                              unsigned long long *__restrict__ row_cnt,
-                                              unsigned long long *__restrict__ loc_cnt)
+// local entry counts per total locus (all entries; gives the file rank inside a locus).  (The per-cell counts used to be taken
+// here too, one global atomic per entry: 2e9 scattered atomics = 94 ms at 1M x 200k.  The row pointers now come out of the
+// cell-sorted keys after the sort, k_row_ptr_from_keys: no atomics.)
+__global__ __launch_bounds__(IB) void k_count(uint64_t n, const uint32_t *__restrict__ locus, unsigned long long *__restrict__ loc_cnt)
 {
     const uint64_t i = (uint64_t)blockIdx.x * IB + threadIdx.x;
     const bool in = i < n;
     const uint32_t l = in ? locus[i] : 0xffffffffu;
-    if (in && to_used[l] != ~0ull) atomicAdd(&row_cnt[cell[i]], 1ull);
     const int lane = threadIdx.x & 63;
     unsigned long long todo = __ballot(in);
     while (todo) {  // one atomic per distinct locus per wave (1-2 iterations on locus-sorted input)
@@ -207,6 +205,18 @@ __global__ __launch_bounds__(IB) void k_count(uint64_t n, const uint32_t *__rest
         if (lane == src) atomicAdd(&loc_cnt[l0], (unsigned long long)__popcll(same));
         todo &= ~same;
     }
+}
+
+// row_ptr[r] = number of sorted keys below r, r = 0..n_rows (rows without entries included): thread i looks at the boundary
+// between keys i-1 and i and writes the pointers of the rows that start there
+__global__ __launch_bounds__(IB) void k_row_ptr_from_keys(uint64_t n, const uint32_t *__restrict__ key_sorted, uint64_t n_rows,
+                                                          uint64_t *__restrict__ row_ptr)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * IB + threadIdx.x;
+    if (i > n) return;
+    const int64_t prev = i > 0 ? (int64_t)key_sorted[i - 1] : -1;
+    const int64_t cur = i < n ? (int64_t)key_sorted[i] : (int64_t)n_rows;
+    for (int64_t r = prev + 1; r <= cur; r++) row_ptr[r] = i;
 }
 
 __global__ void k_gather_used_counts(uint64_t L, const uint64_t *__restrict__ locus_ids,
@@ -412,23 +422,17 @@ cellector_status ingest_build(cellector_ctx *c, uint64_t min_alt, uint64_t min_r
     CHK(dev_alloc(c, &c->csr_ptr, nloc + 1));
     CHK(dev_alloc(c, &loc_cnt, TL + 1));
     CHK(dev_alloc(c, &c->csc_ptr, L + 1));
-    HIPCHK(c, hipMemsetAsync(c->csr_ptr, 0, (nloc + 1) * 8, c->stream));
     HIPCHK(c, hipMemsetAsync(loc_cnt, 0, (TL + 1) * 8, c->stream));
     if (n)
-        hipLaunchKernelGGL(k_count, dim3(g1(n)), dim3(IB), 0, c->stream, n, c->coo_locus, c->coo_cell, c->to_used,
-                           (unsigned long long *)c->csr_ptr, (unsigned long long *)loc_cnt);
+        hipLaunchKernelGGL(k_count, dim3(g1(n)), dim3(IB), 0, c->stream, n, c->coo_locus, (unsigned long long *)loc_cnt);
     HIPCHK(c, hipGetLastError());
     hipLaunchKernelGGL(k_gather_used_counts, dim3(g1(L + 1)), dim3(IB), 0, c->stream, L, c->locus_ids, loc_cnt,
                        c->csc_ptr);
     HIPCHK(c, hipGetLastError());
-    uint64_t nnz_rows = 0, nnz_cols = 0;
-    CHK(dev_exclusive_scan_u64(c, c->csr_ptr, nloc + 1, &nnz_rows));
+    uint64_t nnz_cols = 0;
     CHK(dev_exclusive_scan_u64(c, c->csc_ptr, L + 1, &nnz_cols));
     CHK(dev_exclusive_scan_u64(c, loc_cnt, TL + 1, nullptr));  // now: first file index of each locus
-    if (nnz_rows != nnz_cols)
-        return ctx_fail(c, CELLECTOR_EDEVICE, "internal: CSR/CSC entry counts differ (%llu vs %llu)",
-                        (unsigned long long)nnz_rows, (unsigned long long)nnz_cols);
-    c->nnz = nnz_rows;
+    c->nnz = nnz_cols;
 
     lap("counts + scans");
     // ---- CSC = filtered file order; CSR = stable sort of the same entries by cell
@@ -445,6 +449,8 @@ cellector_status ingest_build(cellector_ctx *c, uint64_t min_alt, uint64_t min_r
     int bits = 1;
     while (bits < 32 && (1ull << bits) < nloc) bits++;
     CHK(dev_sort_pairs_u32_u64(c, key, key_o, val, c->csr_ent, c->nnz, bits));
+    hipLaunchKernelGGL(k_row_ptr_from_keys, dim3(g1(c->nnz + 1)), dim3(IB), 0, c->stream, c->nnz, key_o, nloc, c->csr_ptr);
+    HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(c->stream));
     lap("sort by cell");
     dev_free(key); dev_free(key_o); dev_free(val); dev_free(loc_cnt);
