@@ -282,4 +282,11 @@ struct MtxInput;
 cellector_status mtx_input_open(const cellector_ctx *c, const char *alt_path, const char *ref_path, MtxInput **out,
                                 uint64_t *total_loci, uint64_t *total_cells);
 void mtx_input_close(MtxInput *in);
+// split ingest of a multi-device ctx (kernels_parse.hip): every shard tokenises a range of windows of both files
+struct MtxSplit;
+MtxSplit *mtx_split_new(int n_shards, LocalGroup *thread_barrier);
+void mtx_split_delete(MtxSplit *s);
+bool mtx_input_windowed(const MtxInput *in, int64_t parse_window_opt);
+cellector_status ingest_stage_mtx_split(cellector_ctx *c, MtxInput *in, MtxSplit *s, int rank, uint64_t parse_window, uint32_t **o_locus,
+                                        uint32_t **o_cell, uint16_t **o_alt, uint16_t **o_ref, uint64_t *o_n, bool *o_sorted);
 cellector_status ingest_stage_mtx_device(cellector_ctx *c, MtxInput *in, cellector_ctx *helper = nullptr /*parses the ref file*/);

@@ -492,8 +492,12 @@ cellector_status grow_tokens(cellector_ctx *c, T **arr, uint64_t used, uint64_t 
 // allocated here (capacity from the header's entry count, grown if the file holds more lines)
 template <bool ALT>
 cellector_status parse_windowed(cellector_ctx *c, const FileBytes &fb, size_t data_off, PwBuffers &B, uint64_t cap_hint,
-                                uint32_t **o0, uint32_t **o1, uint32_t **o2, uint64_t *n_lines, unsigned long long *bad)
+                                uint32_t **o0, uint32_t **o1, uint32_t **o2, uint64_t *n_lines, unsigned long long *bad,
+                                uint64_t w_begin = 0, uint64_t w_end = ~0ull)
 {
+    // [w_begin, w_end): the windows this call takes (a multi-device ingest gives every GPU a range of them).  Line indices
+    // are then LOCAL: the number of newlines before the line inside the range; the line that starts right behind the range's
+    // last newline — in the next range's bytes — is still this call's (look-ahead).  *n_lines = newlines in the range.
     const uint64_t window = B.window;
     uint8_t *const *pin = B.pin, *const *dev = B.dev;
     hipEvent_t *ev_up = B.ev_up, *ev_free = B.ev_free;
@@ -510,6 +514,8 @@ cellector_status parse_windowed(cellector_ctx *c, const FileBytes &fb, size_t da
     if (!fb.read(data_off + nb - 1, 1, &last_byte)) return ctx_fail(c, CELLECTOR_EIO, "cannot read the input file");
     const bool unterminated = last_byte != '\n';
     const uint64_t n_win = (nb + window - 1) / window;
+    if (w_end > n_win) w_end = n_win;
+    if (w_begin >= w_end) return CELLECTOR_OK;
     hipError_t e = hipSuccess;
     std::mutex mu;
     std::condition_variable cv;
@@ -520,11 +526,12 @@ cellector_status parse_windowed(cellector_ctx *c, const FileBytes &fb, size_t da
     {
         std::thread producer([&] {
             hipError_t pe = hipSetDevice(c->device);
-            for (uint64_t w = 0; w < n_win && pe == hipSuccess; w++) {
-                const int b = (int)(w % n_ring);
-                if (w >= n_ring) {  // the buffer's previous window has been tokenised
+            for (uint64_t w = w_begin; w < w_end && pe == hipSuccess; w++) {
+                const uint64_t wi = w - w_begin;
+                const int b = (int)(wi % n_ring);
+                if (wi >= n_ring) {  // the buffer's previous window has been tokenised
                     std::unique_lock<std::mutex> lk(mu);
-                    cv.wait(lk, [&] { return consumed + n_ring > w || stop; });
+                    cv.wait(lk, [&] { return consumed + n_ring > wi || stop; });
                     if (stop) return;
                     lk.unlock();
                     pe = hipEventSynchronize(ev_free[b]);
@@ -550,7 +557,7 @@ cellector_status parse_windowed(cellector_ctx *c, const FileBytes &fb, size_t da
                 if (pe != hipSuccess) break;
                 {
                     std::lock_guard<std::mutex> lk(mu);
-                    produced = w + 1;
+                    produced = wi + 1;
                 }
                 cv.notify_all();
             }
@@ -562,16 +569,17 @@ cellector_status parse_windowed(cellector_ctx *c, const FileBytes &fb, size_t da
             cv.notify_all();
         });
         uint64_t line_base = 0;
-        for (uint64_t w = 0; w < n_win && st == CELLECTOR_OK; w++) {
+        for (uint64_t w = w_begin; w < w_end && st == CELLECTOR_OK; w++) {
+            const uint64_t wi = w - w_begin;
             {
                 std::unique_lock<std::mutex> lk(mu);
-                cv.wait(lk, [&] { return produced > w || stop; });
-                if (produced <= w) {
+                cv.wait(lk, [&] { return produced > wi || stop; });
+                if (produced <= wi) {
                     st = ctx_fail(c, CELLECTOR_EDEVICE, "text upload: %s", hipGetErrorString(perr));
                     break;
                 }
             }
-            const int b = (int)(w % n_ring);
+            const int b = (int)(wi % n_ring);
             const uint64_t o = w * window, in_win = std::min<uint64_t>(window, nb - o);
             const uint64_t len = std::min<uint64_t>(window + PW_LOOK, nb - o);
             const bool last = w + 1 == n_win, more = o + len < nb;
@@ -598,7 +606,7 @@ cellector_status parse_windowed(cellector_ctx *c, const FileBytes &fb, size_t da
             if (e != hipSuccess) { st = ctx_fail(c, CELLECTOR_EDEVICE, "parse: %s", hipGetErrorString(e)); break; }
             {
                 std::lock_guard<std::mutex> lk(mu);
-                consumed = w + 1;
+                consumed = wi + 1;
             }
             cv.notify_all();
             line_base += n_nl;
@@ -682,6 +690,238 @@ static cellector_status parse_whole(cellector_ctx *c, const FileBytes &fb, size_
     dev_free(t.text); dev_free(t.seg_off);
     *n_lines = n;
     return st;
+}
+
+// ---- split ingest of a multi-device ctx -------------------------------------------------------------------------------------
+// Every shard tokenises a RANGE OF WINDOWS of both files on its own GPU (its own PCIe link, its own reader threads), then the
+// shards line the two files up and route every entry to the shard that owns its cell:
+//   1. parse: alt windows [k n_win / n, (k+1) n_win / n) -> (locus, cell, count) tokens, ref windows likewise -> counts; a
+//      line's LOCAL index is the number of newlines before it inside the range, so its global index (= its position in the
+//      zip, load_data.rs:190-204) is known once every shard's newline count is: exclusive sums over the ranks;
+//   2. the two files' byte ranges do not cut at the same lines (their lines differ in length): every shard fetches the ref
+//      counts of ITS alt lines from whichever shards tokenised them (contiguous pieces, peer copies);
+//   3. zip + validation of its lines (same kernels as the single-device path), in place -> all-cells COO of those lines;
+//   4. cut by owning cell range (order kept), one piece per destination shard;
+//   5. every shard concatenates the pieces meant for it IN RANK ORDER = file order, which is what load_cell_data's per-cell
+//      lists need (load_data.rs:151-174).
+// The threads meet at a barrier between the steps; a failing shard releases the others (LocalGroup::fail).
+struct MtxSplit {
+    int n = 0;
+    LocalGroup *bar = nullptr;
+    uint64_t ma[CELLECTOR_MAX_SHARDS] = {}, mr[CELLECTOR_MAX_SHARDS] = {};
+    unsigned long long bad_a[CELLECTOR_MAX_SHARDS] = {}, bad_r[CELLECTOR_MAX_SHARDS] = {}, bad_z[CELLECTOR_MAX_SHARDS] = {};
+    uint32_t bad_kind[CELLECTOR_MAX_SHARDS] = {}, unsorted[CELLECTOR_MAX_SHARDS] = {};
+    uint32_t first_locus[CELLECTOR_MAX_SHARDS] = {}, last_locus[CELLECTOR_MAX_SHARDS] = {};
+    uint64_t lines[CELLECTOR_MAX_SHARDS] = {};
+    uint32_t *r_dev[CELLECTOR_MAX_SHARDS] = {};
+    int device[CELLECTOR_MAX_SHARDS] = {};
+    uint32_t *pl[CELLECTOR_MAX_SHARDS][CELLECTOR_MAX_SHARDS] = {}, *pc[CELLECTOR_MAX_SHARDS][CELLECTOR_MAX_SHARDS] = {};
+    uint16_t *pa[CELLECTOR_MAX_SHARDS][CELLECTOR_MAX_SHARDS] = {}, *pr[CELLECTOR_MAX_SHARDS][CELLECTOR_MAX_SHARDS] = {};
+    uint64_t cnt[CELLECTOR_MAX_SHARDS][CELLECTOR_MAX_SHARDS] = {};
+};
+MtxSplit *mtx_split_new(int n, LocalGroup *bar)
+{
+    MtxSplit *S = new (std::nothrow) MtxSplit();
+    if (S) { S->n = n; S->bar = bar; }
+    return S;
+}
+void mtx_split_delete(MtxSplit *S) { delete S; }
+// both files go through the windowed parser (big, or the parse_window option forces it): the split ingest needs that
+bool mtx_input_windowed(const MtxInput *in, int64_t parse_window_opt)
+{
+    const uint64_t na = in->fa.size - in->off_a, nr = in->fr.size - in->off_r;
+    return na > 0 && nr > 0 && (parse_window_opt > 0 || (na >= PW_MIN && nr >= PW_MIN));
+}
+
+static cellector_status copy_between(cellector_ctx *c, void *dst, int dst_dev, const void *src, int src_dev, size_t bytes)
+{
+    if (!bytes) return CELLECTOR_OK;
+    const hipError_t e = dst_dev == src_dev ? hipMemcpy(dst, src, bytes, hipMemcpyDeviceToDevice) : hipMemcpyPeer(dst, dst_dev, src, src_dev, bytes);
+    if (e != hipSuccess) return ctx_fail(c, CELLECTOR_EDEVICE, "copy between shards failed: %s", hipGetErrorString(e));
+    return CELLECTOR_OK;
+}
+
+cellector_status ingest_stage_mtx_split(cellector_ctx *c, MtxInput *in, MtxSplit *S, int rank, uint64_t parse_window, uint32_t **o_locus,
+                                        uint32_t **o_cell, uint16_t **o_alt, uint16_t **o_ref, uint64_t *o_n, bool *o_sorted)
+{
+    const int n = S->n;
+    const uint64_t TL = in->total_loci, TC = in->total_cells;
+    uint32_t *l1 = nullptr, *c1 = nullptr, *a = nullptr, *r = nullptr, *rk = nullptr, *flags = nullptr;
+    uint16_t *alt16 = nullptr, *ref16 = nullptr;
+    unsigned long long *bad = nullptr;
+    uint64_t *keep = nullptr;
+    auto cleanup = [&]() {
+        dev_free(l1); dev_free(c1); dev_free(a); dev_free(r); dev_free(rk); dev_free(flags); dev_free(bad); dev_free(keep);
+        dev_free(alt16); dev_free(ref16);
+        for (int d = 0; d < n; d++) {  // (the pieces this shard cut for the others, if it got that far)
+            dev_free(S->pl[rank][d]); dev_free(S->pc[rank][d]); dev_free(S->pa[rank][d]); dev_free(S->pr[rank][d]);
+            S->pl[rank][d] = S->pc[rank][d] = nullptr; S->pa[rank][d] = S->pr[rank][d] = nullptr;
+        }
+    };
+#define SCHK(expr)                     \
+    do {                               \
+        cellector_status s__ = (expr); \
+        if (s__ != CELLECTOR_OK) {     \
+            cleanup();                 \
+            S->bar->fail();            \
+            return s__;                \
+        }                              \
+    } while (0)
+#define SBARRIER()                                                                                       \
+    do {                                                                                                 \
+        if (!S->bar->barrier()) {                                                                        \
+            cleanup();                                                                                   \
+            return ctx_fail(c, CELLECTOR_ECOMM, "another shard of this ctx failed during the ingest");   \
+        }                                                                                                \
+    } while (0)
+    HIPCHK(c, hipSetDevice(c->device));
+    S->device[rank] = c->device;
+    SCHK(dev_alloc(c, &bad, 3)); SCHK(dev_alloc(c, &flags, 4));
+    unsigned long long h_bad[3] = {~0ull, ~0ull, ~0ull};
+    uint32_t h_flags[4] = {0, 0, 0, 0};
+    hipError_t e = hipMemcpyAsync(bad, h_bad, sizeof h_bad, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(flags, h_flags, sizeof h_flags, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) SCHK(ctx_fail(c, CELLECTOR_EDEVICE, "parse: %s", hipGetErrorString(e)));
+    // ---- 1. this shard's windows of both files
+    uint64_t win = parse_window > 0 ? parse_window : PW_WINDOW;
+    if (win < 4 * NL_SEG) win = 4 * NL_SEG;
+    win &= ~(uint64_t)(NL_SEG - 1);
+    uint64_t ma = 0, mr = 0;
+    {
+        const uint64_t nb_a = in->fa.size - in->off_a, nb_r = in->fr.size - in->off_r;
+        const uint64_t nw_a = (nb_a + win - 1) / win, nw_r = (nb_r + win - 1) / win;
+        const uint64_t hint = in->nnz_hint ? in->nnz_hint / (uint64_t)n + in->nnz_hint / (uint64_t)(8 * n) + 1024 : 0;
+        PwBuffers B;
+        const uint64_t longest = std::max(nw_a, nw_r) / (uint64_t)n + 1;
+        SCHK(B.make(c, win, (int)std::min<uint64_t>(PW_NB, std::max<uint64_t>(1, longest))));
+        // ranges of ceil(n_win / n) windows: rank 0 always holds window 0 (= line 0); late ranks of a short file may hold none
+        const uint64_t pa = (nw_a + n - 1) / n, pr = (nw_r + n - 1) / n;
+        SCHK((parse_windowed<true>(c, in->fa, in->off_a, B, hint ? hint : nb_a / (12 * (uint64_t)n) + 1024, &l1, &c1, &a, &ma, bad,
+                                   std::min(nw_a, pa * rank), std::min(nw_a, pa * (rank + 1)))));
+        SCHK((parse_windowed<false>(c, in->fr, in->off_r, B, hint ? hint : nb_r / (12 * (uint64_t)n) + 1024, (uint32_t **)nullptr,
+                                    (uint32_t **)nullptr, &r, &mr, bad + 1, std::min(nw_r, pr * rank), std::min(nw_r, pr * (rank + 1)))));
+    }
+    e = hipMemcpyAsync(h_bad, bad, sizeof h_bad, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) SCHK(ctx_fail(c, CELLECTOR_EDEVICE, "parse: %s", hipGetErrorString(e)));
+    S->ma[rank] = ma; S->mr[rank] = mr; S->bad_a[rank] = h_bad[0]; S->bad_r[rank] = h_bad[1]; S->r_dev[rank] = r;
+    SBARRIER();
+    // ---- 2. global line numbers; the ref counts of this shard's alt lines
+    uint64_t abase[CELLECTOR_MAX_SHARDS + 1] = {0}, rbase[CELLECTOR_MAX_SHARDS + 1] = {0};
+    for (int k = 0; k < n; k++) { abase[k + 1] = abase[k] + S->ma[k]; rbase[k + 1] = rbase[k] + S->mr[k]; }
+    const uint64_t nlines = std::min(abase[n], rbase[n]);  // izip!: stops at the shorter file
+    {
+        unsigned long long first = ~0ull;  // (a line beyond the shorter file is never read by the reference)
+        for (int k = 0; k < n; k++) {
+            if (S->bad_a[k] != ~0ull) first = std::min<unsigned long long>(first, abase[k] + S->bad_a[k]);
+            if (S->bad_r[k] != ~0ull) first = std::min<unsigned long long>(first, rbase[k] + S->bad_r[k]);
+        }
+        if (first < nlines) {
+            cleanup();
+            (void)S->bar->barrier();  // (every shard sees the same numbers and leaves here: nobody is left waiting)
+            return ctx_fail(c, CELLECTOR_EPARSE, "cannot parse mtx entry %llu (line %llu of the data section)", first, first + 1);
+        }
+    }
+    // lines held by rank k of a file with bases b: global (b[k], b[k] + m[k]] and, for rank 0, line 0; local index = global - b[k]
+    auto g_lo = [&](const uint64_t *b, int k) -> uint64_t { return k == 0 ? (uint64_t)0 : b[k] + 1; };
+    auto g_hi = [&](const uint64_t *b, int k) -> uint64_t { return std::min<uint64_t>(nlines, b[k + 1] + 1); };  // exclusive
+    const uint64_t glo = std::min(g_lo(abase, rank), nlines), ghi = std::max(glo, g_hi(abase, rank));
+    const uint64_t count = ghi - glo, lo = glo - abase[rank];
+    SCHK(dev_alloc(c, &rk, ma + 2));
+    for (int k = 0; k < n; k++) {
+        const uint64_t s0 = std::max(glo, g_lo(rbase, k)), s1 = std::min(ghi, g_hi(rbase, k));
+        if (s0 >= s1) continue;
+        SCHK(copy_between(c, rk + (s0 - abase[rank]), c->device, S->r_dev[k] + (s0 - rbase[k]), S->device[k], (s1 - s0) * sizeof(uint32_t)));
+    }
+    SBARRIER();  // (every shard has fetched what it needs out of the others' ref counts)
+    dev_free(r);
+    S->r_dev[rank] = nullptr;
+    // ---- 3. zip + validation of this shard's lines, in place
+    hipLaunchKernelGGL(k_pair_check, dim3(pgrid(count + 1)), dim3(PB), 0, c->stream, count, l1 + lo, c1 + lo, a + lo, rk + lo, TL, TC,
+                       (uint64_t)0, TC, (uint64_t *)nullptr, bad + 2, flags, flags + 1);
+    uint32_t edge[2] = {0, 0};
+    e = hipMemcpyAsync(h_bad, bad, sizeof h_bad, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(h_flags, flags, sizeof h_flags, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess && count) e = hipMemcpyAsync(&edge[0], l1 + lo, 4, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess && count) e = hipMemcpyAsync(&edge[1], l1 + lo + count - 1, 4, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) SCHK(ctx_fail(c, CELLECTOR_EDEVICE, "parse: %s", hipGetErrorString(e)));
+    S->bad_z[rank] = h_bad[2] == ~0ull ? ~0ull : glo + h_bad[2];
+    S->bad_kind[rank] = h_flags[0]; S->unsorted[rank] = h_flags[1];
+    S->first_locus[rank] = edge[0]; S->last_locus[rank] = edge[1]; S->lines[rank] = count;
+    SBARRIER();
+    {
+        int worst = -1;
+        for (int k = 0; k < n; k++)
+            if (S->bad_z[k] != ~0ull && (worst < 0 || S->bad_z[k] < S->bad_z[worst])) worst = k;
+        if (worst >= 0) {
+            static const char *what[] = {"", "index 0 (indices are 1-based)", "locus index out of range", "cell index out of range",
+                                         "count above 65535 not supported"};
+            cleanup();
+            (void)S->bar->barrier();
+            return ctx_fail(c, CELLECTOR_EINVAL, "mtx entry %llu: %s", S->bad_z[worst], what[S->bad_kind[worst] <= 4 ? S->bad_kind[worst] : 0]);
+        }
+        bool sorted = true;
+        uint32_t prev_last = 0;
+        bool have_prev = false;
+        for (int k = 0; k < n; k++) {
+            if (S->unsorted[k]) sorted = false;
+            if (!S->lines[k]) continue;
+            if (have_prev && S->first_locus[k] < prev_last) sorted = false;  // (1-based tokens on both sides)
+            prev_last = S->last_locus[k];
+            have_prev = true;
+        }
+        *o_sorted = sorted;
+    }
+    SCHK(dev_alloc(c, &alt16, count)); SCHK(dev_alloc(c, &ref16, count));
+    if (count) hipLaunchKernelGGL(k_pair_take, dim3(pgrid(count)), dim3(PB), 0, c->stream, count, l1 + lo, c1 + lo, a + lo, rk + lo, alt16, ref16);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) SCHK(ctx_fail(c, CELLECTOR_EDEVICE, "parse: %s", hipGetErrorString(e)));
+    // ---- 4. one piece per destination shard (cells of its range, order kept, cell index local to it)
+    {
+        // (ingest_split_coo reads the staged COO of a ctx: lend it the arrays for the calls; this ctx has staged nothing yet)
+        c->coo_locus = l1 + lo; c->coo_cell = c1 + lo; c->coo_alt = alt16; c->coo_ref = ref16; c->coo_n = count;
+        cellector_status st = dev_alloc(c, &keep, count + 1);
+        const uint64_t per = comm_cells_per_rank(TC, n);
+        for (int d = 0; d < n && st == CELLECTOR_OK; d++) {
+            const uint64_t cb = std::min<uint64_t>(TC, (uint64_t)d * per), ce = std::min<uint64_t>(TC, cb + per);
+            st = ingest_split_coo(c, cb, ce, keep, &S->pl[rank][d], &S->pc[rank][d], &S->pa[rank][d], &S->pr[rank][d], &S->cnt[rank][d]);
+        }
+        c->coo_locus = c->coo_cell = nullptr; c->coo_alt = c->coo_ref = nullptr; c->coo_n = 0;
+        SCHK(st);
+    }
+    SBARRIER();
+    // ---- 5. this shard's entries = the pieces meant for it, in rank order (= file order)
+    uint64_t total = 0;
+    for (int k = 0; k < n; k++) total += S->cnt[k][rank];
+    uint32_t *fl = nullptr, *fc = nullptr;
+    uint16_t *fa16 = nullptr, *fr16 = nullptr;
+    cellector_status st = dev_alloc(c, &fl, total);
+    if (st == CELLECTOR_OK) st = dev_alloc(c, &fc, total);
+    if (st == CELLECTOR_OK) st = dev_alloc(c, &fa16, total);
+    if (st == CELLECTOR_OK) st = dev_alloc(c, &fr16, total);
+    uint64_t at = 0;
+    for (int k = 0; k < n && st == CELLECTOR_OK; k++) {
+        const uint64_t m = S->cnt[k][rank];
+        st = copy_between(c, fl + at, c->device, S->pl[k][rank], S->device[k], m * 4);
+        if (st == CELLECTOR_OK) st = copy_between(c, fc + at, c->device, S->pc[k][rank], S->device[k], m * 4);
+        if (st == CELLECTOR_OK) st = copy_between(c, fa16 + at, c->device, S->pa[k][rank], S->device[k], m * 2);
+        if (st == CELLECTOR_OK) st = copy_between(c, fr16 + at, c->device, S->pr[k][rank], S->device[k], m * 2);
+        at += m;
+    }
+    if (st != CELLECTOR_OK) { dev_free(fl); dev_free(fc); dev_free(fa16); dev_free(fr16); SCHK(st); }
+    if (!S->bar->barrier()) {  // (the pieces this shard made have been fetched by their destinations)
+        dev_free(fl); dev_free(fc); dev_free(fa16); dev_free(fr16);
+        cleanup();
+        return ctx_fail(c, CELLECTOR_ECOMM, "another shard of this ctx failed during the ingest");
+    }
+    cleanup();
+    *o_locus = fl; *o_cell = fc; *o_alt = fa16; *o_ref = fr16; *o_n = total;
+#undef SCHK
+#undef SBARRIER
+    return CELLECTOR_OK;
 }
 
 // Stage this shard's entries of the alt/ref pair on the device; dims / shard range must already be set on the ctx.

@@ -79,6 +79,11 @@ static cellector_status run_all(const cellector_ctx *root, std::function<cellect
         std::unique_lock<std::mutex> lk(m->mu);
         m->cv_done.wait(lk, [&] { return m->pending == 0; });
     }
+    {   // every worker is back: a failure that released the others from a barrier must not poison the next call
+        std::lock_guard<std::mutex> lk(m->local.mu);
+        m->local.failed = false;
+        m->local.arrived = 0;
+    }
     for (size_t r = 0; r < m->shards.size(); r++)
         if (m->result[r] != CELLECTOR_OK) {
             root->err = "shard " + std::to_string(r) + " (device " + std::to_string(m->shards[r]->device) + "): " + m->shards[r]->err;
@@ -177,14 +182,63 @@ cellector_status multi_set_option(cellector_ctx *root, const char *key, int64_t 
 // time (the two are independent byte streams until they are zipped line by line); its entries are then cut by owning cell range
 // (file order kept) and every piece goes to its shard's device (peer copy over xGMI; a plain device copy between logical
 // shards of one GPU).  n shards each parsing the whole pair would read the text n times on the host and push it over n PCIe
-// links at once: slower than one GPU from a few shards on.  (Parsing 1/n of the bytes per GPU is the scalable form — it
-// needs the two files' line numbers matched across byte ranges — and is not built.)
+// links at once: slower than one GPU from a few shards on.  From three devices on every GPU parses 1/n of the bytes instead
+// (the split ingest at the top of the function).
 cellector_status multi_ingest_mtx(cellector_ctx *root, const char *alt_path, const char *ref_path)
 {
     MultiCtx *m = root->multi;
     if (getenv("CELLECTOR_MULTI_PARSE_EACH"))  // (A/B: every shard parses the pair itself)
         return run_all(root, [=](cellector_ctx *s, int) { return cellector_ingest_mtx(s, alt_path, ref_path); });
     cellector_ctx *s0 = m->shards[0];
+    // ---- split ingest: every GPU tokenises 1/n of both files' bytes and the entries are routed to their owners
+    // (kernels_parse.hip, ingest_stage_mtx_split).  Taken when the shards sit on at least three different devices (with two,
+    // "alt here, ref there" below already uses both links) and both files are big enough for the windowed parser;
+    // CELLECTOR_MULTI_SPLIT=1 forces it (tests on logical shards of one GPU), =0 switches it off.
+    {
+        int distinct = 0;
+        for (size_t i = 0; i < m->shards.size(); i++) {
+            bool seen = false;
+            for (size_t j = 0; j < i; j++) seen = seen || m->shards[j]->device == m->shards[i]->device;
+            distinct += seen ? 0 : 1;
+        }
+        const char *env = getenv("CELLECTOR_MULTI_SPLIT");
+        const bool want = env ? atoi(env) != 0 : distinct >= 3;
+        if (want) {
+            MtxInput *in = nullptr;
+            uint64_t tl = 0, tc = 0;
+            if (hipSetDevice(s0->device) != hipSuccess) return ctx_fail(root, CELLECTOR_EDEVICE, "hipSetDevice failed");
+            cellector_status st = mtx_input_open(s0, alt_path, ref_path, &in, &tl, &tc);
+            if (st != CELLECTOR_OK) { root->err = s0->err; return st; }
+            if (mtx_input_windowed(in, s0->parse_window_opt)) {
+                const int n = (int)m->shards.size();
+                LocalGroup bar;
+                bar.n = n;
+                MtxSplit *S = mtx_split_new(n, &bar);
+                if (!S) { mtx_input_close(in); return ctx_fail(root, CELLECTOR_ENOMEM, "out of host memory"); }
+                const uint64_t window = s0->parse_window_opt > 0 ? (uint64_t)s0->parse_window_opt : 0;
+                st = run_all(root, [=](cellector_ctx *s, int rank) {
+                    uint32_t *pl = nullptr, *pc = nullptr;
+                    uint16_t *pa = nullptr, *pr = nullptr;
+                    uint64_t cnt = 0;
+                    bool sorted = false;
+                    cellector_status r = ingest_stage_mtx_split(s, in, S, rank, window, &pl, &pc, &pa, &pr, &cnt, &sorted);
+                    if (r != CELLECTOR_OK) return r;
+                    return ffi_adopt_staged(s, tl, tc, pl, pc, pa, pr, cnt, sorted);
+                });
+                if (st == CELLECTOR_ECOMM)  // (report the shard that failed, not one of those it released)
+                    for (size_t r = 0; r < m->shards.size(); r++)
+                        if (m->result[r] != CELLECTOR_OK && m->result[r] != CELLECTOR_ECOMM) {
+                            root->err = "shard " + std::to_string(r) + " (device " + std::to_string(m->shards[r]->device) + "): " + m->shards[r]->err;
+                            st = m->result[r];
+                            break;
+                        }
+                mtx_split_delete(S);
+                mtx_input_close(in);
+                return st;
+            }
+            mtx_input_close(in);  // (small files: one parser is enough)
+        }
+    }
     auto fail = [&](cellector_ctx *s, cellector_status st) {
         root->err = "shard (device " + std::to_string(s->device) + "): " + s->err;
         return st;

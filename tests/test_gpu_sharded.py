@@ -114,6 +114,86 @@ def test_multi_device_ctx_equals_single_ctx_and_oracle(devices, oracle_lib, hip_
     single.close()
 
 
+def test_split_text_ingest_every_shard_parses_a_byte_range(hip_lib_path, tmp_path):
+    """From three devices on, every GPU of a multi-device ctx tokenises 1/n of BOTH files' bytes (window ranges), the shards
+    line the files up by global line number, zip, validate and route every entry to the shard that owns its cell
+    (kernels_parse.hip: ingest_stage_mtx_split).  CELLECTOR_MULTI_SPLIT=1 runs it on logical shards of one GPU with tiny windows:
+    alt and ref ranges never cut at the same lines (different header, different digit counts), the last line is unterminated,
+    late shards get no window at all for a short file.  The staged matrix (file order inside every cell), the EM results and the
+    error reports must be those of a single-device ctx."""
+    from cellector_amd import Cellector, ffi, synth
+    L, N = 700, 901
+    lo, ce, al, re = synth.generate_coo(L, N, 0.05, seed=23, minority_fraction=0.08)
+    al = al.copy(); al[::7] += 12345  # longer tokens in one file than in the other
+    a_path, r_path = synth.write_mtx_pair(str(tmp_path), L, N, lo, ce, al, re)
+    with open(a_path, "rb") as f:
+        body = f.read()
+    with open(a_path, "wb") as f:
+        f.write(body.rstrip(b"\n"))
+    ref_lines = open(r_path).read().split("\n", 3)
+    open(r_path, "w").write(ref_lines[0] + "\n% a longer comment line than the alt file has, to shift every window\n" + ref_lines[2] + "\n" + ref_lines[3])
+    single = Cellector(0)
+    single.load_mtx(a_path, r_path, 2, 2)
+    rs, es = single.csr_rows(0, N)
+    it_single = [single.em_iteration(5.0) for _ in range(3)]
+    os.environ["CELLECTOR_MULTI_SPLIT"] = "1"
+    try:
+        for n_shards, window in ((3, 4096), (5, 512), (7, 1 << 15), (2, 640)):
+            m = Cellector(devices=[0] * n_shards)
+            m.set_option("parse_window", window)
+            m.load_mtx(a_path, r_path, 2, 2)
+            dm, ds = m.dims(), single.dims()
+            assert (dm.total_loci, dm.total_cells, dm.loci_used, dm.nnz_used) == (ds.total_loci, ds.total_cells, ds.loci_used, ds.nnz_used)
+            assert np.array_equal(m.locus_ids(), single.locus_ids())
+            assert np.array_equal(m.locus_counts(), single.locus_counts())
+            rm, em = m.csr_rows(0, N)
+            assert np.array_equal(rm, rs) and np.array_equal(em, es), (n_shards, window)
+            for s1 in it_single:
+                sm = m.em_iteration(5.0)
+                assert (sm.threshold, sm.median, sm.iqr, sm.n_excluded, sm.n_loci_filtered) == \
+                       (s1.threshold, s1.median, s1.iqr, s1.n_excluded, s1.n_loci_filtered)
+            m.close()
+        # a file that is not locus-major, and a ref file shorter than the alt file (the zip stops there, load_data.rs:190)
+        rng = np.random.default_rng(5)
+        perm = rng.permutation(len(lo))
+        b_alt, b_ref = synth.write_mtx_pair(str(tmp_path / "perm"), L, N, lo[perm], ce[perm], al[perm], re[perm])
+        keep = len(lo) - 777
+        with open(b_ref) as f:
+            lines = f.read().split("\n")
+        open(b_ref, "w").write("\n".join(lines[:3 + keep]) + "\n")
+        single2 = Cellector(0)
+        single2.load_mtx(b_alt, b_ref, 2, 2)
+        m = Cellector(devices=[0] * 4)
+        m.set_option("parse_window", 2048)
+        m.load_mtx(b_alt, b_ref, 2, 2)
+        assert m.dims().nnz_used == single2.dims().nnz_used
+        r1, e1 = single2.csr_rows(0, N)
+        r2, e2 = m.csr_rows(0, N)
+        assert np.array_equal(r1, r2) and np.array_equal(e1, e2)
+        s1, s2 = single2.em_iteration(5.0), m.em_iteration(5.0)
+        assert (s1.threshold, s1.n_excluded) == (s2.threshold, s2.n_excluded)
+        single2.close()
+        # errors: same status and entry number as the single-device parser, from whichever shard meets them; nobody hangs
+        many = "".join(f"1 {1 + i % 3} 1\n" for i in range(1500))
+        cases = {"float": (many + "1 1 1.0\n" + many, 3, 1500), "two_tokens": (many + many + "1 1\n", 3, 3000),
+                 "index0": (many + "0 1 1\n" + many, 1, 1500), "cell_range": ("1 4 1\n" + many + many, 1, 0),
+                 "count_range": (many + many + "1 1 70000\n", 1, 3000), "first_of_two": (many + "x\n" + many + "y\n", 3, 1500)}
+        for name, (text, status, where) in cases.items():
+            bad = tmp_path / f"split_{name}.mtx"
+            bad.write_text("%%MatrixMarket\n%\n2 3 0\n" + text)
+            with pytest.raises(ffi.CellectorError) as ei:
+                m.load_mtx(str(bad), str(bad), 1, 1)
+            assert ei.value.status == status and f"entry {where}" in str(ei.value), (name, str(ei.value))
+        # ... and the ctx is still usable afterwards
+        m.load_mtx(a_path, r_path, 2, 2)
+        rm, em = m.csr_rows(0, N)
+        assert np.array_equal(rm, rs) and np.array_equal(em, es)
+        m.close()
+    finally:
+        os.environ.pop("CELLECTOR_MULTI_SPLIT", None)
+    single.close()
+
+
 def test_more_shards_than_cells_and_errors(hip_lib_path, tmp_path):
     """shards without cells, and an error inside one shard must come back as an error (not hang the others)"""
     from cellector_amd import Cellector, ffi, synth
