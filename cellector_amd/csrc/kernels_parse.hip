@@ -431,6 +431,7 @@ cellector_status split_lines(cellector_ctx *c, const FileBytes &fb, DevText *dt)
 #define PW_LOOK (1ull << 20)  // the longest line a windowed file may hold
 #define PW_NB 3
 #define PW_WINDOW (256ull << 20)
+#define PW_SPLIT_WINDOW (32ull << 20)  // largest window of the split ingest of a multi-device ctx (every shard has its own ring)
 #define PW_MIN (1ull << 30)  // data sections from this size on go through the windows
 #define PW_THREADS 8  // host threads filling a pinned buffer (pread out of the page cache; 16 threads measured no faster)
 
@@ -776,6 +777,14 @@ cellector_status ingest_stage_mtx_split(cellector_ctx *c, MtxInput *in, MtxSplit
     } while (0)
     HIPCHK(c, hipSetDevice(c->device));
     S->device[rank] = c->device;
+    const bool timing = rank == 0 && getenv("CELLECTOR_TIMING") != nullptr;  // phase wall times of shard 0 on stderr
+    auto t_prev = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!timing) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[timing]     split: %-26s %8.3f s\n", what, std::chrono::duration<double>(now - t_prev).count());
+        t_prev = now;
+    };
     SCHK(dev_alloc(c, &bad, 3)); SCHK(dev_alloc(c, &flags, 4));
     unsigned long long h_bad[3] = {~0ull, ~0ull, ~0ull};
     uint32_t h_flags[4] = {0, 0, 0, 0};
@@ -784,7 +793,12 @@ cellector_status ingest_stage_mtx_split(cellector_ctx *c, MtxInput *in, MtxSplit
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess) SCHK(ctx_fail(c, CELLECTOR_EDEVICE, "parse: %s", hipGetErrorString(e)));
     // ---- 1. this shard's windows of both files
-    uint64_t win = parse_window > 0 ? parse_window : PW_WINDOW;
+    // (n shards pin their upload buffers at the same time and the driver pins them one after the other: 4 x 3 x 256 MB took
+    //  0.2-0.5 s per shard on one box — 4 logical shards, 2 x 2.9 GB: 1.1 s with 256 MB windows, 0.32 s with 16 MB)
+    uint64_t win = std::max(in->fa.size - in->off_a, in->fr.size - in->off_r) / ((uint64_t)n * 32);
+    win = std::min<uint64_t>(PW_SPLIT_WINDOW, std::max<uint64_t>(16ull << 20, win));
+    if (const char *e_mb = getenv("CELLECTOR_SPLIT_WINDOW_MB")) win = (uint64_t)atoll(e_mb) << 20;  // (tools/split_check.sh)
+    if (parse_window > 0) win = parse_window;
     if (win < 4 * NL_SEG) win = 4 * NL_SEG;
     win &= ~(uint64_t)(NL_SEG - 1);
     uint64_t ma = 0, mr = 0;
@@ -795,18 +809,23 @@ cellector_status ingest_stage_mtx_split(cellector_ctx *c, MtxInput *in, MtxSplit
         PwBuffers B;
         const uint64_t longest = std::max(nw_a, nw_r) / (uint64_t)n + 1;
         SCHK(B.make(c, win, (int)std::min<uint64_t>(PW_NB, std::max<uint64_t>(1, longest))));
+        lap("upload buffers");
         // ranges of ceil(n_win / n) windows: rank 0 always holds window 0 (= line 0); late ranks of a short file may hold none
         const uint64_t pa = (nw_a + n - 1) / n, pr = (nw_r + n - 1) / n;
         SCHK((parse_windowed<true>(c, in->fa, in->off_a, B, hint ? hint : nb_a / (12 * (uint64_t)n) + 1024, &l1, &c1, &a, &ma, bad,
                                    std::min(nw_a, pa * rank), std::min(nw_a, pa * (rank + 1)))));
+        lap("alt range (upload + tokens)");
         SCHK((parse_windowed<false>(c, in->fr, in->off_r, B, hint ? hint : nb_r / (12 * (uint64_t)n) + 1024, (uint32_t **)nullptr,
                                     (uint32_t **)nullptr, &r, &mr, bad + 1, std::min(nw_r, pr * rank), std::min(nw_r, pr * (rank + 1)))));
+        lap("ref range (upload + tokens)");
     }
     e = hipMemcpyAsync(h_bad, bad, sizeof h_bad, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess) SCHK(ctx_fail(c, CELLECTOR_EDEVICE, "parse: %s", hipGetErrorString(e)));
     S->ma[rank] = ma; S->mr[rank] = mr; S->bad_a[rank] = h_bad[0]; S->bad_r[rank] = h_bad[1]; S->r_dev[rank] = r;
+    lap("release buffers");
     SBARRIER();
+    lap("wait for the other shards");
     // ---- 2. global line numbers; the ref counts of this shard's alt lines
     uint64_t abase[CELLECTOR_MAX_SHARDS + 1] = {0}, rbase[CELLECTOR_MAX_SHARDS + 1] = {0};
     for (int k = 0; k < n; k++) { abase[k + 1] = abase[k] + S->ma[k]; rbase[k + 1] = rbase[k] + S->mr[k]; }
@@ -835,6 +854,7 @@ cellector_status ingest_stage_mtx_split(cellector_ctx *c, MtxInput *in, MtxSplit
         SCHK(copy_between(c, rk + (s0 - abase[rank]), c->device, S->r_dev[k] + (s0 - rbase[k]), S->device[k], (s1 - s0) * sizeof(uint32_t)));
     }
     SBARRIER();  // (every shard has fetched what it needs out of the others' ref counts)
+    lap("fetch ref counts");
     dev_free(r);
     S->r_dev[rank] = nullptr;
     // ---- 3. zip + validation of this shard's lines, in place
@@ -892,6 +912,7 @@ cellector_status ingest_stage_mtx_split(cellector_ctx *c, MtxInput *in, MtxSplit
         c->coo_locus = c->coo_cell = nullptr; c->coo_alt = c->coo_ref = nullptr; c->coo_n = 0;
         SCHK(st);
     }
+    lap("zip + cut by owner");
     SBARRIER();
     // ---- 5. this shard's entries = the pieces meant for it, in rank order (= file order)
     uint64_t total = 0;
@@ -918,6 +939,7 @@ cellector_status ingest_stage_mtx_split(cellector_ctx *c, MtxInput *in, MtxSplit
         return ctx_fail(c, CELLECTOR_ECOMM, "another shard of this ctx failed during the ingest");
     }
     cleanup();
+    lap("gather own pieces");
     *o_locus = fl; *o_cell = fc; *o_alt = fa16; *o_ref = fr16; *o_n = total;
 #undef SCHK
 #undef SBARRIER
@@ -995,7 +1017,13 @@ cellector_status ingest_stage_mtx_device(cellector_ctx *c, MtxInput *in, cellect
     // a multi-GB file goes through the device in windows (option parse_window forces a window size: tests); the token
     // arrays' capacity comes from the size line's entry count (a hint only: the reference never reads it)
     uint64_t n_a = 0, n_r = 0;
-    uint64_t win = c->parse_window_opt > 0 ? (uint64_t)c->parse_window_opt : PW_WINDOW;
+    // window: 1/96 of the bigger file, 32 MB .. PW_WINDOW.  (Pinning and releasing 3 x 256 MB of upload buffers is 0.1-0.15 s
+    // of a 0.39 s ingest of 2 x 2.9 GB: 32 MB windows take 0.245 s there; at 2 x 31 GB the window size makes no difference,
+    // 256 MB stays.  tools/window_sweep.sh)
+    uint64_t win = std::max(fa.size - off_a, fr.size - off_r) / 96;
+    win = std::min<uint64_t>(PW_WINDOW, std::max<uint64_t>(32ull << 20, win));
+    if (const char *e_mb = getenv("CELLECTOR_WINDOW_MB")) win = (uint64_t)atoll(e_mb) << 20;  // (the sweep)
+    if (c->parse_window_opt > 0) win = (uint64_t)c->parse_window_opt;
     if (win < 4 * NL_SEG) win = 4 * NL_SEG;
     win &= ~(uint64_t)(NL_SEG - 1);
     const bool win_a = c->parse_window_opt > 0 || !fa.data || fa.size - off_a >= PW_MIN;
