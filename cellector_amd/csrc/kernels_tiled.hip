@@ -136,6 +136,12 @@ __global__ __launch_bounds__(64 * TB_PARTS) void k_build_tables(uint64_t L, uint
 #endif
 // Workgroup barrier that waits for this wave's LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it would wait
 // for the prefetch loads in flight and make them synchronous.
+#ifndef TILE_PF4
+// 1: rows requested four steps (= one chunk) ahead when a column has four blocks, 0: two steps.  Measured at cfg4: the kernel
+// itself 1.955 -> 1.87 ms, but at 123 VGPRs (97 with two buffers) its four waves per SIMD take the whole register file, the
+// overflow kernels of the side stream find no room beside it and run behind it instead: cell pass 2.02 -> 2.26 ms.  Off.
+#define TILE_PF4 0
+#endif
 #define TILE_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
 struct __attribute__((packed, aligned(4))) tile_u4 { uint32_t x, y, z, w; };  // 16-byte load at a 4-byte aligned address
@@ -221,8 +227,11 @@ __global__ __launch_bounds__(T_THREADS, 4) void k_tile_ll(uint32_t nb, uint32_t 
         (E).hi = *reinterpret_cast<const tile_u4 *>((E).ptr + ((H).z > 7u ? 8u : 0u));                           \
     } while (0)
 
-    uint4 h0, h1;   // at the top of an even step t: slice headers of steps t+2 (h0) and t+3 (h1)
-    row_t e0, e1;   // at the top of an even step t: rows of steps t (e0) and t+1 (e1)
+    // PFD = prefetch distance in steps = number of pipeline buffers.  With four blocks per column every block of the chunk has
+    // a buffer of its own and the rows are requested a whole chunk ahead.
+    constexpr uint32_t PFD = (T_SB == 4 && TILE_PF4) ? 4u : 2u;
+    uint4 h0, h1, h2, h3;   // at the top of step t (t % PFD == 0): slice headers of steps t+PFD (h0), t+PFD+1 (h1), ...
+    row_t e0, e1, e2, e3;   // at the top of step t (t % PFD == 0): rows of steps t (e0), t+1 (e1), ...
     // The table loads are the OLDEST requests when the chunk loop is entered, like on its back edge, so that the wait
     // for them is a counted vmcnt that leaves the younger row requests in flight (the scheduler must not move them
     // behind the loads below: vmcnt counts in issue order).
@@ -230,10 +239,13 @@ __global__ __launch_bounds__(T_THREADS, 4) void k_tile_ll(uint32_t nb, uint32_t 
     __builtin_amdgcn_sched_barrier(0);
     HDR_LOAD(h0, 0);
     HDR_LOAD(h1, 1);
+    if constexpr (PFD == 4) { HDR_LOAD(h2, 2); HDR_LOAD(h3, 3); }
     ROW_LOAD(e0, h0);
     ROW_LOAD(e1, h1);
-    HDR_LOAD(h0, 2);
-    HDR_LOAD(h1, 3);
+    if constexpr (PFD == 4) { ROW_LOAD(e2, h2); ROW_LOAD(e3, h3); }
+    HDR_LOAD(h0, PFD);
+    HDR_LOAD(h1, PFD + 1);
+    if constexpr (PFD == 4) { HDR_LOAD(h2, PFD + 2); HDR_LOAD(h3, PFD + 3); }
     uint32_t t = 0;
 
     // one step: block S of the current chunk, pipeline buffers E / H
@@ -277,14 +289,14 @@ __global__ __launch_bounds__(T_THREADS, 4) void k_tile_ll(uint32_t nb, uint32_t 
     } else { TILE_ADD(PA); TILE_ADD(PB); }
 #define TILE_STEP(S, E, H)                                                                                       \
     do {                                                                                                         \
-        /* 1. consume the row requested two steps ago: u16 number i of the row sits in half i & 1 of dword i >> 1 */ \
+        /* 1. consume the row requested PFD steps ago: u16 number i of the row sits in half i & 1 of dword i >> 1 */ \
         const uint32_t w__[8] = {(E).lo.x, (E).lo.y, (E).lo.z, (E).lo.w, (E).hi.x, (E).hi.y, (E).hi.z, (E).hi.w}; \
         const uint32_t K__ = (uint32_t)__builtin_amdgcn_readfirstlane((int)(E).k); /* wave-uniform, odd */       \
         const uint16_t *cur__ = (E).ptr;                                                                         \
         const uint32_t cell__ = w__[0] & 0xffffu;                                                                \
-        /* 2. issue the next requests: rows of step t+2 (their header is here), header of step t+4 */            \
+        /* 2. issue the next requests: rows of step t+PFD (their header is here), header of step t+2 PFD */      \
         ROW_LOAD(E, H);                                                                                          \
-        HDR_LOAD(H, t + 4);                                                                                      \
+        HDR_LOAD(H, t + 2 * PFD);                                                                                \
         /* 3. the cell's accumulator is requested first (LDS answers in order: it has landed when the sums are done), */ \
         /*    then this lane's cell of the slice: K lookups for every lane (padding entries hit the zero row) */  \
         tab_t acc__ = s_acc[(S) * T_BC + cell__];                                                                \
@@ -336,7 +348,10 @@ __global__ __launch_bounds__(T_THREADS, 4) void k_tile_ll(uint32_t nb, uint32_t 
         TILE_BARRIER();  // table visible
         TILE_STEP(0, e0, h0);
         TILE_STEP(1, e1, h1);
-        if constexpr (T_SB == 4) {
+        if constexpr (T_SB == 4 && PFD == 4) {
+            TILE_STEP(2, e2, h2);
+            TILE_STEP(3, e3, h3);
+        } else if constexpr (T_SB == 4) {
             TILE_STEP(2, e0, h0);
             TILE_STEP(3, e1, h1);
         }
