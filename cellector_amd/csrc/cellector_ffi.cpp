@@ -281,7 +281,7 @@ void cellector_destroy(cellector_ctx *c)
     c->ev_pool.clear();
     free_matrix(c);
     dev_free(c->lf); dev_free(c->d_counters); dev_free(c->sel_hist); dev_free(c->sel_state); dev_free(c->sel_out);
-    dev_free(c->sel_list);
+    dev_free(c->sel_list); dev_free(c->seld_hist); dev_free(c->seld_state);
     if (c->h_sel) (void)hipHostFree(c->h_sel);
     if (c->side) (void)hipStreamDestroy(c->side);
     if (c->stream && c->owns_stream) (void)hipStreamDestroy(c->stream);
@@ -335,6 +335,7 @@ cellector_status cellector_set_option(cellector_ctx *c, const char *key, int64_t
         if (c->tiled_ready && v >= 0) c->ovf_deep = v != 0;
     }
     else if (!strcmp(key, "norm_zero")) c->norm_zero = v != 0;
+    else if (!strcmp(key, "sharded_select")) c->sharded_select = v < 0 ? -1 : (v != 0);
     else if (!strcmp(key, "parse_window")) c->parse_window_opt = v < 0 ? 0 : v;
     else if (!strcmp(key, "tile_groups")) {
         if (v < 0 || v > 64 || v % 8) return ctx_fail(c, CELLECTOR_EINVAL, "tile_groups must be 0 (automatic) or a multiple of 8 up to 64");
@@ -740,10 +741,17 @@ cellector_status cellector_em_threshold(cellector_ctx *c, double iqr_multiple)
     SETDEV(c);
     const uint64_t n = c->total_cells;
     REQUIRE(c, n > 0, "no cells");
-    // exchange point 2 (a ctx with a communicator does it itself): every shard's slice of the normalised LLs
-    if (comm_active(c->comm)) CHK((cellector_status)comm_allgather_slices(c, c->x_norm, comm_cells_per_rank(n, c->comm.n)));
-    // exact median / R-8 quartiles / threshold, all on the device (no host round trip in this phase)
-    CHK(select_threshold(c, c->x_norm, n, iqr_multiple));
+    // exact median / R-8 quartiles / threshold, all on the device (no host round trip in this phase).
+    // Exchange point 2: a ctx with a communicator runs the radix select over the shards' keys where they are and exchanges
+    // digit histograms (six all-reduces of 48 KB); option sharded_select = 0 gathers every shard's slice of the normalised
+    // LLs instead and selects over all of them on every shard.  (A host that runs the exchanges itself gathers NORM before
+    // this call.)
+    if (comm_active(c->comm) && comm_sharded_select(c->comm, c->sharded_select)) {
+        CHK(select_threshold_sharded(c, c->x_norm + c->cell_begin, c->nloc, n, iqr_multiple));
+    } else {
+        if (comm_active(c->comm)) CHK((cellector_status)comm_allgather_slices(c, c->x_norm, comm_cells_per_rank(n, c->comm.n)));
+        CHK(select_threshold(c, c->x_norm, n, iqr_multiple));
+    }
     // (the counters k_flag adds to were reset by this iteration's k_alpha_beta)
     CHK(launch_flag(c, c->sel_out + 10));
     if (c->engine == 2) CHK(tiled_locus_pass(c));
@@ -1004,6 +1012,37 @@ cellector_status cellector_kernel_time(cellector_ctx *c, cellector_kernel_id whi
     if (total_ms) *total_ms = c->timers[which].total_ms;
     if (launches) *launches = c->timers[which].launches;
     return CELLECTOR_OK;
+}
+
+}  // extern "C"
+// (a shard of a multi-device ctx is handed its slice of the keys; n_total = all keys)
+cellector_status ffi_order_statistics(cellector_ctx *c, const double *keys, uint64_t n_local, uint64_t n_total, double iqr_multiple, double *out3)
+{
+    REQUIRE(c, n_total > 0 && (keys || !n_local), "order statistics: no keys");
+    SETDEV(c);
+    double *d_keys = nullptr;
+    CHK(dev_alloc(c, &d_keys, n_local ? n_local : 1));
+    cellector_status st = CELLECTOR_OK;
+    if (n_local && hipMemcpyAsync(d_keys, keys, n_local * 8, hipMemcpyHostToDevice, c->stream) != hipSuccess)
+        st = ctx_fail(c, CELLECTOR_EDEVICE, "upload of the keys failed");
+    if (st == CELLECTOR_OK)
+        st = comm_active(c->comm) && comm_sharded_select(c->comm, c->sharded_select) ? select_threshold_sharded(c, d_keys, n_local, n_total, iqr_multiple)
+                                                       : select_threshold(c, d_keys, n_local, iqr_multiple);
+    if (st == CELLECTOR_OK && out3) st = d2h(c, out3, c->sel_out + 8, 3 * sizeof(double));
+    else (void)hipStreamSynchronize(c->stream);
+    dev_free(d_keys);
+    return st;
+}
+
+extern "C" {
+
+cellector_status cellector_order_statistics(cellector_ctx *c, const double *keys, uint64_t n, double iqr_multiple, double *out3)
+{
+    if (!c) return CELLECTOR_EINVAL;
+    if (c->multi) return multi_order_statistics(c, keys, n, iqr_multiple, out3);
+    REQUIRE(c, !comm_active(c->comm) || c->comm.n == 1,
+            "order statistics on one rank of a communicator: every rank would have to call with its slice");
+    return ffi_order_statistics(c, keys, n, n, iqr_multiple, out3);
 }
 
 cellector_status cellector_reset_timing(cellector_ctx *c)

@@ -22,7 +22,7 @@ struct LocalGroup {
     std::condition_variable cv;
     int arrived = 0;
     uint64_t generation = 0;
-    const double *bufs[CELLECTOR_MAX_SHARDS] = {};
+    const void *bufs[CELLECTOR_MAX_SHARDS] = {};
     bool failed = false;  // a shard gave up (error path): the others must not wait for it
     bool barrier();       // false: the group has failed
     void fail();
@@ -41,9 +41,16 @@ static inline bool comm_active(const Comm &m) { return m.n > 1 || m.nccl != null
 // cells per rank of the canonical contiguous split (the NORM all-gather needs equal slots)
 static inline uint64_t comm_cells_per_rank(uint64_t total_cells, int n) { return (total_cells + (uint64_t)n - 1) / (uint64_t)n; }
 
+// Exchange point 2 by digit histograms or by gathering the keys?  Six levels (kernel + all-reduce of 48 KB) cost ~0.08 ms of
+// kernels (measured, 10^6 keys per shard) plus six small-message latencies; the gathering form moves 8 B per cell of the WHOLE
+// run to every shard and selects over all of them there (0.054 ms per 10^6 keys, measured).  With two ranks the gather is the
+// cheaper one, from three on the histograms (estimate: no multi-GPU box was available to measure the collectives).
+static inline bool comm_sharded_select(const Comm &m, int option) { return option >= 0 ? option != 0 : m.n != 2; }
+
 int comm_status_ok();  // CELLECTOR_OK as int (keeps this header free of the public one)
 // sum over all shards, in place, on the ctx's stream; every shard ends with the same bits
 int comm_allreduce_sum(cellector_ctx *c, double *buf, uint64_t count);
+int comm_allreduce_sum_u32(cellector_ctx *c, uint32_t *buf, uint64_t count);  // (counts: the order statistics of a sharded run)
 // every shard contributes buf[rank*per .. +per) and receives the others' slices (buf holds n*per doubles)
 int comm_allgather_slices(cellector_ctx *c, double *buf, uint64_t per);
 // RCCL: unique id for ncclCommInitRank, communicator set-up / tear-down

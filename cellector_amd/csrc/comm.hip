@@ -151,37 +151,41 @@ void LocalGroup::fail()
         if (!(g)->barrier()) return (int)ctx_fail((c), CELLECTOR_ECOMM, "another shard of this ctx failed"); \
     } while (0)
 
-struct peer_bufs_t { const double *p[CELLECTOR_MAX_SHARDS]; };
+struct peer_bufs_t { const void *p[CELLECTOR_MAX_SHARDS]; };
 // out[i] = sum over the shards' buffers in rank order: every shard computes the same bits
-__global__ __launch_bounds__(256) void k_sum_peers(uint64_t n, int n_peers, peer_bufs_t peers, double *__restrict__ out)
+template <typename T>
+__global__ __launch_bounds__(256) void k_sum_peers(uint64_t n, int n_peers, peer_bufs_t peers, T *__restrict__ out)
 {
     const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    double s = peers.p[0][i];
-    for (int r = 1; r < n_peers; r++) s += peers.p[r][i];
+    T s = static_cast<const T *>(peers.p[0])[i];
+    for (int r = 1; r < n_peers; r++) s += static_cast<const T *>(peers.p[r])[i];
     out[i] = s;
 }
 
-static int local_allreduce(cellector_ctx *c, double *buf, uint64_t count)
+template <typename T>
+static int local_allreduce(cellector_ctx *c, T *buf, uint64_t count)
 {
     LocalGroup *g = c->comm.local;
-    if (c->comm.tmp_n < count) {
+    const uint64_t need = (count * sizeof(T) + 7) / 8;  // (the scratch is kept in doubles)
+    if (c->comm.tmp_n < need) {
         dev_free(c->comm.tmp);
         c->comm.tmp_n = 0;
-        if (dev_alloc(c, &c->comm.tmp, count) != CELLECTOR_OK) return (int)CELLECTOR_ENOMEM;
-        c->comm.tmp_n = count;
+        if (dev_alloc(c, &c->comm.tmp, need) != CELLECTOR_OK) return (int)CELLECTOR_ENOMEM;
+        c->comm.tmp_n = need;
     }
+    T *tmp = reinterpret_cast<T *>(c->comm.tmp);
     HIPCHK(c, hipStreamSynchronize(c->stream));  // this shard's contribution is complete
     g->bufs[c->comm.rank] = buf;
     BARRIER(c, g);
     peer_bufs_t peers;
     for (int r = 0; r < g->n; r++) peers.p[r] = g->bufs[r];
     if (count)
-        hipLaunchKernelGGL(k_sum_peers, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, c->stream, count, g->n, peers, c->comm.tmp);
+        hipLaunchKernelGGL(k_sum_peers<T>, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, c->stream, count, g->n, peers, tmp);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(c->stream));
     BARRIER(c, g);  // everybody has read everybody's contribution
-    if (count) HIPCHK(c, hipMemcpyAsync(buf, c->comm.tmp, count * 8, hipMemcpyDeviceToDevice, c->stream));
+    if (count) HIPCHK(c, hipMemcpyAsync(buf, tmp, count * sizeof(T), hipMemcpyDeviceToDevice, c->stream));
     return (int)CELLECTOR_OK;
 }
 
@@ -193,7 +197,8 @@ static int local_allgather(cellector_ctx *c, double *buf, uint64_t per)
     BARRIER(c, g);
     for (int r = 0; r < g->n; r++)
         if (r != c->comm.rank && per)
-            HIPCHK(c, hipMemcpyAsync(buf + (uint64_t)r * per, g->bufs[r] + (uint64_t)r * per, per * 8, hipMemcpyDeviceToDevice, c->stream));
+            HIPCHK(c, hipMemcpyAsync(buf + (uint64_t)r * per, static_cast<const double *>(g->bufs[r]) + (uint64_t)r * per, per * 8,
+                                     hipMemcpyDeviceToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     BARRIER(c, g);  // nobody overwrites a slice another shard still copies
     return (int)CELLECTOR_OK;
@@ -206,6 +211,15 @@ int comm_allreduce_sum(cellector_ctx *c, double *buf, uint64_t count)
     if (c->comm.local) return local_allreduce(c, buf, count);
     if (!c->comm.nccl) return (int)ctx_fail(c, CELLECTOR_ECOMM, "sharded ctx without a communicator");
     NCCLCHK(c, g_rccl.AllReduce(buf, buf, (size_t)count, ncclDouble, ncclSum, (ncclComm_t)c->comm.nccl, c->stream));
+    return (int)CELLECTOR_OK;
+}
+
+int comm_allreduce_sum_u32(cellector_ctx *c, uint32_t *buf, uint64_t count)
+{
+    if (!comm_active(c->comm)) return (int)CELLECTOR_OK;
+    if (c->comm.local) return local_allreduce(c, buf, count);
+    if (!c->comm.nccl) return (int)ctx_fail(c, CELLECTOR_ECOMM, "sharded ctx without a communicator");
+    NCCLCHK(c, g_rccl.AllReduce(buf, buf, (size_t)count, ncclUint32, ncclSum, (ncclComm_t)c->comm.nccl, c->stream));
     return (int)CELLECTOR_OK;
 }
 

@@ -65,6 +65,9 @@ struct cellector_ctx {
     bool compute_expected = true;
     int64_t parse_window_opt = 0;  // option parse_window: 0 = whole file below 1 GB, 256 MB windows above; else the window in bytes
     int tile_groups_opt = 0;  // option tile_groups: 0 = chosen per matrix (tiled_setup), else forced (multiple of 8)
+    // option sharded_select: a ctx with a communicator exchanges digit histograms (1) or all-gathers NORM (0); -1 = by the
+    // number of ranks (use_sharded_select)
+    int sharded_select = -1;
     bool norm_zero = true;  // option: clear the other shards' slices of NORM before the cell pass (needed by a sum exchange)
     int timing = 0;  // 0 off, 1 every timed region, 2 only the dominant kernel of the engine
     bool keep_coo = true;
@@ -169,6 +172,8 @@ struct cellector_ctx {
     uint64_t *sel_list = nullptr;   // keys that carry a target's 22-bit prefix (capacity: all keys)
     uint64_t sel_list_cap = 0;
     double *sel_out = nullptr;      // [16] device: [0..5] order statistics, [8..10] median, iqr, threshold
+    uint32_t *seld_hist = nullptr;  // sharded run: [6 levels][SEL_T][2048] digit histograms (select_threshold_sharded), made on first use
+    uint64_t *seld_state = nullptr; // ... [7][SEL_T][2] prefix, remaining rank before / after every level
     double *h_sel = nullptr;        // pinned [32]: iteration summary written by k_iter_summary, read in em_finish
     double *h_sum_dev = nullptr;    // the device's address of h_sel
     uint64_t sum_seq = 0;           // number of summaries queued; h_sel[CELLECTOR_SUM_SEQ] = the last one that arrived
@@ -251,6 +256,10 @@ cellector_status launch_posteriors(cellector_ctx *c, double mf0, double lp_min, 
 cellector_status launch_final_tallies(cellector_ctx *c, uint64_t *d_out /*[4*total_loci]*/);
 // order statistics: exact values at SEL_T 0-based ranks of n keys
 cellector_status select_threshold(cellector_ctx *c, const double *keys, uint64_t n, double iqr_multiple);
+cellector_status ffi_order_statistics(cellector_ctx *c, const double *keys, uint64_t n_local, uint64_t n_total, double iqr_multiple,
+                                      double *out3);  // (cellector_ffi.cpp; a shard's slice of cellector_order_statistics)
+// ... over the keys of all shards of a sharded run (this shard holds n_local of the n_total), exchanged as digit histograms
+cellector_status select_threshold_sharded(cellector_ctx *c, const double *keys, uint64_t n_local, uint64_t n_total, double iqr_multiple);
 // ingest
 cellector_status ingest_stage_host_coo(cellector_ctx *c, uint64_t nnz, const uint32_t *locus0,
                                        const uint32_t *cell0, const uint32_t *alt, const uint32_t *ref);

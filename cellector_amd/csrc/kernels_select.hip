@@ -517,3 +517,187 @@ cellector_status select_threshold(cellector_ctx *c, const double *keys, uint64_t
     HIPCHK(c, hipGetLastError());
     return CELLECTOR_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// The same order statistics over the keys of ALL shards of a sharded run, every shard holding only its own cells' keys
+// (select_threshold_sharded; the exchange layer of comm.h).  MSB-first radix select again, but nothing is gathered: the 64 key
+// bits are resolved in six levels of 11, 11, 11, 11, 10 and 10 bits; a level is one kernel over the shard's keys (the step on
+// the previous level's histograms, summed over the shards, then the histogram of the next digit of the keys that carry a
+// target's resolved prefix) and one all-reduce of 48 KB of counts.  After the sixth level a target's key is known bit for bit:
+// every shard computes the same threshold, with a fixed number of small collectives instead of an all-gather of all keys and
+// a select over all of them on every shard (8 B per cell of the whole run per iteration, and work that does not shrink with
+// the shard).
+// ---------------------------------------------------------------------------------------------------------
+#define SELD_LEVELS 6
+#define SELD_NB 2048
+__device__ __constant__ int SELD_SHIFT[SELD_LEVELS] = {53, 42, 31, 20, 10, 0};
+__device__ __constant__ int SELD_BITS[SELD_LEVELS] = {11, 11, 11, 11, 10, 10};
+
+// the step on level (L - 1)'s summed histograms: state_in (prefix, remaining rank per target) -> st[] in LDS; a wave per target
+__device__ __forceinline__ void seld_step(int level_prev, const uint32_t *__restrict__ hist_prev, const uint64_t *__restrict__ state_in,
+                                          uint64_t *st /*[2 * SEL_T] in LDS*/)
+{
+    if (threadIdx.x < 64 * SEL_T) {
+        const int lane = (int)threadIdx.x & 63, t = (int)threadIdx.x >> 6;
+        uint64_t p[SEL_T];
+        int ld[SEL_T];
+#pragma unroll
+        for (int u = 0; u < SEL_T; u++) p[u] = state_in[2 * u];
+        sel_leaders(p, ld);
+        int mine = 0;
+        uint64_t pt = 0;
+#pragma unroll
+        for (int u = 0; u < SEL_T; u++)
+            if (u == t) { mine = ld[u]; pt = p[u]; }
+        const uint64_t r = state_in[2 * t + 1];
+        const uint32_t *hist = hist_prev + mine * SELD_NB;
+        uint64_t lsum, inc, below;
+        uint32_t bin;
+        sel_scan<SELD_NB>(lane, hist, lsum, inc);
+        sel_pick<SELD_NB>(lane, hist, lsum, inc, r, bin, below);
+        if (lane == 0) {
+            st[2 * t] = pt | ((uint64_t)bin << SELD_SHIFT[level_prev]);
+            st[2 * t + 1] = r - below;
+        }
+    }
+}
+
+template <bool FIRST>
+__global__ __launch_bounds__(SEL_THREADS) void k_seld_level(const double *__restrict__ keys, uint64_t n, int level, sel_ranks_t ranks,
+                                                            const uint32_t *__restrict__ hist_prev, const uint64_t *__restrict__ state_in,
+                                                            uint64_t *__restrict__ state_out, uint32_t *__restrict__ hist_out)
+{
+    __shared__ uint32_t h[FIRST ? 1 : SEL_T][SELD_NB];
+    __shared__ uint64_t st[2 * SEL_T];
+    for (int i = threadIdx.x; i < (FIRST ? 1 : SEL_T) * SELD_NB; i += SEL_THREADS) (&h[0][0])[i] = 0;
+    if constexpr (!FIRST) {
+        seld_step(level - 1, hist_prev, state_in, st);
+        __syncthreads();
+        if (blockIdx.x == 0 && threadIdx.x < 2 * SEL_T) state_out[threadIdx.x] = st[threadIdx.x];
+    } else {
+        // nothing is resolved yet: all targets share histogram 0; the step on it is taken by level 1
+        if (blockIdx.x == 0 && threadIdx.x < SEL_T) { state_out[2 * threadIdx.x] = 0; state_out[2 * threadIdx.x + 1] = ranks.r[threadIdx.x]; }
+        __syncthreads();
+    }
+    const int shift = SELD_SHIFT[level], bits = SELD_BITS[level];
+    const uint32_t dmask = (1u << bits) - 1u;
+    uint64_t hi[SEL_T];
+    bool lead[SEL_T];
+    if constexpr (!FIRST) {
+        uint64_t p[SEL_T];
+        int ld[SEL_T];
+#pragma unroll
+        for (int t = 0; t < SEL_T; t++) p[t] = st[2 * t];
+        sel_leaders(p, ld);
+#pragma unroll
+        for (int t = 0; t < SEL_T; t++) { hi[t] = p[t] >> (shift + bits); lead[t] = ld[t] == t; }
+    }
+    const int lane = threadIdx.x & 63;
+    const uint64_t stride = (uint64_t)gridDim.x * SEL_THREADS;
+    for (uint64_t base = (uint64_t)blockIdx.x * SEL_THREADS; base < n; base += SEL_UNROLL * stride) {
+        uint64_t k[SEL_UNROLL];
+        bool ok[SEL_UNROLL];
+#pragma unroll
+        for (int u = 0; u < SEL_UNROLL; u++) {
+            const uint64_t i = base + u * stride + threadIdx.x;
+            ok[u] = i < n;
+            k[u] = ok[u] ? key_of(keys[i]) : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < SEL_UNROLL; u++) {
+            const uint32_t d = (uint32_t)(k[u] >> shift) & dmask;
+            if constexpr (FIRST) {  // sign + exponent bits: a handful of bins, a wave whose keys agree votes with one atomic
+                const unsigned long long act = __ballot(ok[u]);
+                if (!act) continue;  // wave-uniform
+                const int src = __ffsll((long long)act) - 1;
+                const uint32_t d0 = (uint32_t)__shfl((int)d, src, 64);
+                const unsigned long long same = __ballot(ok[u] && d == d0);
+                if (same == act) {
+                    if (lane == src) atomicAdd(&h[0][d0], (uint32_t)__popcll(act));
+                } else if (ok[u]) {
+                    atomicAdd(&h[0][d], 1u);
+                }
+            } else {
+                if (!ok[u]) continue;
+                const uint64_t kh = k[u] >> (shift + bits);
+#pragma unroll
+                for (int t = 0; t < SEL_T; t++)
+                    if (lead[t] && kh == hi[t]) atomicAdd(&h[t][d], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < (FIRST ? 1 : SEL_T) * SELD_NB; i += SEL_THREADS) {
+        const uint32_t v = (&h[0][0])[i];
+        if (v) atomicAdd(&hist_out[i], v);
+    }
+}
+
+// the step on the last level's histograms: the six keys, bit for bit; then the threshold arithmetic of k_sel_finish
+__global__ __launch_bounds__(64 * SEL_T) void k_seld_finish(sel_quart_t q, const uint32_t *__restrict__ hist_prev,
+                                                            const uint64_t *__restrict__ state_in, double *__restrict__ v,
+                                                            double *__restrict__ out)
+{
+    __shared__ uint64_t st[2 * SEL_T];
+    seld_step(SELD_LEVELS - 1, hist_prev, state_in, st);
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    double w[SEL_T];
+#pragma unroll
+    for (int t = 0; t < SEL_T; t++) { w[t] = value_of(st[2 * t]); v[t] = w[t]; }
+    const double median = (q.n % 2 != 0) ? w[1] : (w[0] + w[1]) / 2.0;
+    double q1, q3;
+    if (q.hf1 <= 0) q1 = w[3]; else if (q.hf1 >= (int64_t)q.n) q1 = w[2]; else q1 = w[2] + (q.h1 - (double)q.hf1) * (w[3] - w[2]);
+    if (q.hf3 <= 0) q3 = w[5]; else if (q.hf3 >= (int64_t)q.n) q3 = w[4]; else q3 = w[4] + (q.h3 - (double)q.hf3) * (w[5] - w[4]);
+    const double iqr = q3 - q1;
+    out[0] = median;
+    out[1] = iqr;
+    out[2] = q1 - q.iqr_multiple * iqr;  // main.rs:328-329
+}
+
+// keys = this shard's n_local keys, n_total = the keys of all shards; results as select_threshold (identical on every shard)
+cellector_status select_threshold_sharded(cellector_ctx *c, const double *keys, uint64_t n_local, uint64_t n_total, double iqr_multiple)
+{
+    const uint64_t n = n_total;
+    if (n == 0) return ctx_fail(c, CELLECTOR_EINVAL, "order statistics of an empty array");
+    if (n > 0xffffffffull) return ctx_fail(c, CELLECTOR_EINVAL, "order statistics: more than 2^32 - 1 keys");
+    const uint64_t k = n / 2;
+    sel_quart_t q;
+    q.h1 = ((double)n + 1.0 / 3.0) * 0.25 + 1.0 / 3.0;
+    q.h3 = ((double)n + 1.0 / 3.0) * 0.75 + 1.0 / 3.0;
+    q.hf1 = (int64_t)q.h1;
+    q.hf3 = (int64_t)q.h3;
+    q.n = n;
+    q.iqr_multiple = iqr_multiple;
+    auto clampr = [n](int64_t r) -> uint64_t { return r < 0 ? 0 : ((uint64_t)r >= n ? n - 1 : (uint64_t)r); };
+    const uint64_t ranks[SEL_T] = {k ? k - 1 : 0, k, clampr(q.hf1 - 1), clampr(q.hf1), clampr(q.hf3 - 1), clampr(q.hf3)};
+    constexpr uint64_t HW = (uint64_t)SEL_T * SELD_NB;  // histogram words of a level
+    if (!c->seld_hist) {
+        CHK(dev_alloc(c, &c->seld_hist, SELD_LEVELS * HW));
+        CHK(dev_alloc(c, &c->seld_state, (uint64_t)(SELD_LEVELS + 1) * 2 * SEL_T));
+    }
+    sel_ranks_t r;
+    for (int t = 0; t < SEL_T; t++) r.r[t] = ranks[t];
+    timer_begin(c, CELLECTOR_K_SELECT);
+    HIPCHK(c, hipMemsetAsync(c->seld_hist, 0, SELD_LEVELS * HW * sizeof(uint32_t), c->stream));
+    uint64_t g = (n_local + SEL_THREADS * SEL_UNROLL - 1) / (SEL_THREADS * SEL_UNROLL);
+    if (g > SEL_GRID) g = SEL_GRID;
+    if (g == 0) g = 1;  // (a shard without cells still takes the steps: it writes no state anybody reads, but keeps the kernels uniform)
+    for (int level = 0; level < SELD_LEVELS; level++) {
+        uint32_t *hist = c->seld_hist + (uint64_t)level * HW;
+        const uint32_t *prev = level ? c->seld_hist + (uint64_t)(level - 1) * HW : nullptr;
+        const uint64_t *s_in = c->seld_state + (uint64_t)level * 2 * SEL_T;
+        uint64_t *s_out = c->seld_state + (uint64_t)(level + 1) * 2 * SEL_T;
+        if (level == 0)
+            hipLaunchKernelGGL(k_seld_level<true>, dim3((unsigned)g), dim3(SEL_THREADS), 0, c->stream, keys, n_local, level, r, prev, s_in, s_out, hist);
+        else
+            hipLaunchKernelGGL(k_seld_level<false>, dim3((unsigned)g), dim3(SEL_THREADS), 0, c->stream, keys, n_local, level, r, prev, s_in, s_out, hist);
+        HIPCHK(c, hipGetLastError());
+        CHK((cellector_status)comm_allreduce_sum_u32(c, hist, level == 0 ? SELD_NB : HW));
+    }
+    hipLaunchKernelGGL(k_seld_finish, dim3(1), dim3(64 * SEL_T), 0, c->stream, q, c->seld_hist + (uint64_t)(SELD_LEVELS - 1) * HW,
+                       c->seld_state + (uint64_t)SELD_LEVELS * 2 * SEL_T, c->sel_out, c->sel_out + 8);
+    timer_end(c, CELLECTOR_K_SELECT);
+    HIPCHK(c, hipGetLastError());
+    return CELLECTOR_OK;
+}

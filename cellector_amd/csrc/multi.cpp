@@ -441,6 +441,22 @@ cellector_status multi_engine_info(const cellector_ctx *root, cellector_engine_i
     return CELLECTOR_OK;
 }
 
+cellector_status multi_order_statistics(cellector_ctx *root, const double *keys, uint64_t n, double iqr_multiple, double *out3)
+{
+    if (!n || !keys) return ctx_fail(root, CELLECTOR_EINVAL, "order statistics: no keys");
+    const int ns = (int)root->multi->shards.size();
+    const uint64_t per = comm_cells_per_rank(n, ns);
+    // (always the sharded select: the gathering form works on the loaded matrix's NORM buffers)
+    return run_all(root, [=](cellector_ctx *s, int rank) {
+        const uint64_t b = std::min(n, (uint64_t)rank * per), e = std::min(n, b + per);
+        const int keep = s->sharded_select;
+        s->sharded_select = 1;
+        const cellector_status st = ffi_order_statistics(s, keys + b, e - b, n, iqr_multiple, rank == 0 ? out3 : nullptr);
+        s->sharded_select = keep;
+        return st;
+    });
+}
+
 cellector_status multi_reset_timing(cellector_ctx *root)
 {
     for (cellector_ctx *s : root->multi->shards) (void)cellector_reset_timing(s);

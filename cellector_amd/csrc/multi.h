@@ -25,3 +25,4 @@ cellector_status multi_em_iteration(cellector_ctx *root, double iqr_multiple, ce
 cellector_status multi_final_allele_tallies(cellector_ctx *root, uint64_t *alt_min, uint64_t *ref_min, uint64_t *alt_maj, uint64_t *ref_maj);
 cellector_status multi_engine_info(const cellector_ctx *root, cellector_engine_info_t *o);
 cellector_status multi_reset_timing(cellector_ctx *root);
+cellector_status multi_order_statistics(cellector_ctx *root, const double *keys, uint64_t n, double iqr_multiple, double *out3);

@@ -57,6 +57,7 @@ SIGNATURES = {
     "cellector_posteriors": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "cellector_final_allele_tallies": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "cellector_engine_info": (_i, [_vp, _vp]),
+    "cellector_order_statistics": (_i, [_vp, _vp, _u64, _d, _vp]),
     "cellector_kernel_time": (_i, [_vp, _i, C.POINTER(_d), C.POINTER(_u64)]),
     "cellector_reset_timing": (_i, [_vp]),
 }
@@ -325,6 +326,13 @@ class Cellector:
         e = EngineInfo()
         self._ck(self._lib.cellector_engine_info(self.h, C.byref(e)))
         return e
+
+    def order_statistics(self, keys, iqr_multiple=5.0):
+        """(median, iqr, threshold) of the keys by the device select (a multi-device ctx: the sharded select)."""
+        keys = np.ascontiguousarray(keys, dtype=np.float64)
+        out = np.zeros(3, dtype=np.float64)
+        self._ck(self._lib.cellector_order_statistics(self.h, keys.ctypes.data, len(keys), float(iqr_multiple), out.ctypes.data))
+        return tuple(out.tolist())
 
     # ---- timing
     def kernel_time(self, which):

@@ -99,7 +99,11 @@ cellector_status cellector_set_stream(cellector_ctx *ctx, void *hip_stream);
  * "synth_continue_pct" (default 30: cellector_ingest_synthetic draws an entry's total as 1 + Geometric(0.7), vartrix-like
  * shallow coverage; a larger value gives deeper counts, e.g. 60 = 1 + Geometric(0.4) — benchmarks of the count distribution),
  * "norm_zero" (default 1: a shard clears the other shards' slices of CELLECTOR_XCHG_NORM before it writes
- * its own, so that a SUM all-reduce completes the array; 0 when the caller all-gathers the slices). */
+ * its own, so that a SUM all-reduce completes the array; 0 when the caller all-gathers the slices),
+ * "sharded_select" (1: a ctx with a communicator — cellector_create_multi, cellector_comm_init_rank — finds the
+ * median / quartiles by a radix select over the shards' own keys, exchanging digit histograms: six all-reduces of 48 KB per
+ * iteration; 0: every shard's normalised LLs are all-gathered and every shard selects over all of them; default -1: the
+ * gather with two ranks, the histograms otherwise; same bits either way). */
 cellector_status cellector_set_option(cellector_ctx *ctx, const char *key, int64_t value);
 
 /* ---- sharding (before ingest) --------------------------------------------------------------- */
@@ -240,6 +244,14 @@ typedef struct {
                                of the sliced-ELLPACK rows (each lookup = one or two 8-byte LDS reads)              */
 } cellector_engine_info_t;
 cellector_status cellector_engine_info(const cellector_ctx *ctx, cellector_engine_info_t *out);
+
+/* ---- the order statistics by themselves ----------------------------------------------------- */
+/* Median, interquartile range and threshold (statrs Data::median / quantile and main.rs:324-329) of n caller-supplied keys
+ * (host array, no NaN): what the scoring loop computes from the normalised log-likelihoods, as a call of its own (tests of the
+ * select on keys no run produces; no matrix needs to be loaded).  A multi-device ctx spreads the keys over its shards the
+ * way it spreads cells and runs the sharded select (see option sharded_select).  out3 = {median, iqr, threshold}. */
+cellector_status cellector_order_statistics(cellector_ctx *ctx, const double *keys, uint64_t n, double iqr_multiple,
+                                            double *out3);
 
 /* ---- timing of the dominant kernels (HIP events on the ctx stream; option "timing") ---------- */
 typedef enum {

@@ -48,6 +48,8 @@ def test_multi_device_ctx_equals_single_ctx_and_oracle(devices, oracle_lib, hip_
     single.load_coo(L, N, *coo)
     for source in ("coo", "mtx"):
         m = Cellector(devices=devices)
+        # exchange point 2 both ways per shard count: digit histograms, or NORM all-gather + select over all keys
+        m.set_option("sharded_select", 1 if source == "coo" else 0)
         if source == "coo":
             m.load_coo(L, N, *coo)
         else:
@@ -242,6 +244,44 @@ def test_rccl_transport_single_rank_selftest(hip_lib_path):
             assert np.array_equal(lg[k], lp[k]), k
         assert np.array_equal(g.posteriors()["posterior"], p.posteriors()["posterior"])
     g.close()
+
+
+def test_sharded_order_statistics_on_adversarial_keys(oracle_lib, hip_lib_path):
+    """A ctx with a communicator finds the median / quartiles without gathering the keys: every shard histograms its own
+    keys digit by digit and the counts are all-reduced (kernels_select.hip: select_threshold_sharded).  On keys no EM run
+    produces — ties, one shared prefix, every exponent, tiny n, shards without a key — the result must be bit-identical to the
+    oracle's statrs restatement and to the single-device select; through the device-side sums of logical shards and through
+    RCCL with one rank."""
+    from cellector_amd import Cellector, ffi
+    ob = oracle_lib
+    rng = np.random.default_rng(7)
+    cases = [
+        np.array([-0.25]), np.array([3.0, -1.0]), np.array([0.0, -0.0, -1e-310]), np.array([-1.0, -1.0, -1.0, -2.0]),
+        np.full(5000, -0.5), np.where(rng.random(5000) < 0.5, -0.5, -0.75), -0.5 - np.arange(40000) * 1e-13,
+        -rng.uniform(0.25, 1.0, 40000), rng.standard_normal(40000) * 10.0 ** rng.integers(-300, 300, 40000),
+        np.round(rng.standard_normal(40000), 1), -np.exp(rng.standard_normal(300000) * 0.2) * 0.5,
+        np.concatenate([np.zeros(100000), -rng.uniform(0.4, 0.6, 200001)]),
+        np.sort(rng.standard_normal(100003)),          # sorted: every shard holds one range of values
+        np.concatenate([np.full(70000, 1.5), rng.standard_normal(30000)]),  # the first shards hold nothing but one value
+    ]
+    single = Cellector(0)
+    os.environ["CELLECTOR_COMM_SELFTEST"] = "1"
+    try:
+        one_rank = Cellector(0)
+        one_rank.comm_init_rank(ffi.comm_unique_id(), 1, 0)
+    finally:
+        os.environ.pop("CELLECTOR_COMM_SELFTEST", None)
+    groups = [Cellector(devices=[0] * k) for k in (2, 3, 7)]
+    for keys in cases:
+        keys = np.ascontiguousarray(keys, dtype=np.float64)
+        q1, q3 = ob.quantile(keys, 0.25), ob.quantile(keys, 0.75)
+        want = (ob.median(keys), q3 - q1, q1 - 5.0 * (q3 - q1))
+        assert single.order_statistics(keys, 5.0) == want, len(keys)
+        assert one_rank.order_statistics(keys, 5.0) == want, len(keys)
+        for m in groups:
+            assert m.order_statistics(keys, 5.0) == want, len(keys)
+    for g in groups + [single, one_rank]:
+        g.close()
 
 
 def test_bench_contract_on_cfg1():
