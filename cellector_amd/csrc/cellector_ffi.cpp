@@ -746,7 +746,7 @@ cellector_status cellector_em_threshold(cellector_ctx *c, double iqr_multiple)
     // digit histograms (six all-reduces of 48 KB); option sharded_select = 0 gathers every shard's slice of the normalised
     // LLs instead and selects over all of them on every shard.  (A host that runs the exchanges itself gathers NORM before
     // this call.)
-    if (comm_active(c->comm) && comm_sharded_select(c->comm, c->sharded_select)) {
+    if (comm_active(c->comm) && comm_sharded_select(c->comm, c->sharded_select, n)) {
         CHK(select_threshold_sharded(c, c->x_norm + c->cell_begin, c->nloc, n, iqr_multiple));
     } else {
         if (comm_active(c->comm)) CHK((cellector_status)comm_allgather_slices(c, c->x_norm, comm_cells_per_rank(n, c->comm.n)));
@@ -1026,7 +1026,7 @@ cellector_status ffi_order_statistics(cellector_ctx *c, const double *keys, uint
     if (n_local && hipMemcpyAsync(d_keys, keys, n_local * 8, hipMemcpyHostToDevice, c->stream) != hipSuccess)
         st = ctx_fail(c, CELLECTOR_EDEVICE, "upload of the keys failed");
     if (st == CELLECTOR_OK)
-        st = comm_active(c->comm) && comm_sharded_select(c->comm, c->sharded_select) ? select_threshold_sharded(c, d_keys, n_local, n_total, iqr_multiple)
+        st = comm_active(c->comm) && comm_sharded_select(c->comm, c->sharded_select, n_total) ? select_threshold_sharded(c, d_keys, n_local, n_total, iqr_multiple)
                                                        : select_threshold(c, d_keys, n_local, iqr_multiple);
     if (st == CELLECTOR_OK && out3) st = d2h(c, out3, c->sel_out + 8, 3 * sizeof(double));
     else (void)hipStreamSynchronize(c->stream);

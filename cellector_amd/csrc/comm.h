@@ -42,10 +42,14 @@ static inline bool comm_active(const Comm &m) { return m.n > 1 || m.nccl != null
 static inline uint64_t comm_cells_per_rank(uint64_t total_cells, int n) { return (total_cells + (uint64_t)n - 1) / (uint64_t)n; }
 
 // Exchange point 2 by digit histograms or by gathering the keys?  Six levels (kernel + all-reduce of 48 KB) cost ~0.08 ms of
-// kernels (measured, 10^6 keys per shard) plus six small-message latencies; the gathering form moves 8 B per cell of the WHOLE
-// run to every shard and selects over all of them there (0.054 ms per 10^6 keys, measured).  With two ranks the gather is the
-// cheaper one, from three on the histograms (estimate: no multi-GPU box was available to measure the collectives).
-static inline bool comm_sharded_select(const Comm &m, int option) { return option >= 0 ? option != 0 : m.n != 2; }
+// kernels at 10^6 keys per shard (measured) plus six small-message latencies, whatever the size of the run; the gathering form
+// moves 8 B per cell of the WHOLE run to every shard and selects over all of them there (0.054 ms per 10^6 keys, measured).
+// BASELINE's 10^6 cells are 8 MB: one all-gather and one select are then the cheaper side; from 4*10^6 cells (32 MB) on the
+// histograms are.  (An estimate: no multi-GPU box was available to measure the collectives.)
+static inline bool comm_sharded_select(const Comm &m, int option, uint64_t total_cells)
+{
+    return option >= 0 ? option != 0 : (m.n > 2 && total_cells >= (4ull << 20)) || m.n == 1 /* self-test: run the new path */;
+}
 
 int comm_status_ok();  // CELLECTOR_OK as int (keeps this header free of the public one)
 // sum over all shards, in place, on the ctx's stream; every shard ends with the same bits

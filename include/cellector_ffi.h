@@ -103,7 +103,7 @@ cellector_status cellector_set_stream(cellector_ctx *ctx, void *hip_stream);
  * "sharded_select" (1: a ctx with a communicator — cellector_create_multi, cellector_comm_init_rank — finds the
  * median / quartiles by a radix select over the shards' own keys, exchanging digit histograms: six all-reduces of 48 KB per
  * iteration; 0: every shard's normalised LLs are all-gathered and every shard selects over all of them; default -1: the
- * gather with two ranks, the histograms otherwise; same bits either way). */
+ * histograms for runs of 4 Mi cells and more on three or more ranks, else the gather; same bits either way). */
 cellector_status cellector_set_option(cellector_ctx *ctx, const char *key, int64_t value);
 
 /* ---- sharding (before ingest) --------------------------------------------------------------- */
