@@ -269,6 +269,18 @@ def main():
     ti_ms, ti_n = g.kernel_time(ffi.K_TILE_LL)
     ll_avg = ll_ms / max(ll_n, 1)
     n_loc = ce - cb
+    # ---- the posterior phase (phases are timed separately): calculate_posteriors = three log-likelihood passes
+    # with three alpha/beta sets over all loci + the per-cell finalize, on the device (no output copies) and as the host sees
+    # it (4 x 8 B per cell copied back); untimed for the headline figure
+    post_ms = {}
+    for name, fetch in (("device", False), ("with_output_copy", True)):
+        g.posteriors(fetch=fetch)
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(3):
+            g.posteriors(fetch=fetch)
+        fence()
+        post_ms[name] = (time.perf_counter() - t1) / 3 * 1e3
     info = g.engine_info()
     # Dominant kernel and the entries ONE launch of it processes on this rank:
     #   engine 2: k_tile_ll, the regular entries (1 <= alt+ref <= 4); engine 1: k_cell_ll, all entries.
@@ -341,6 +353,7 @@ def main():
                                       + (f"; {comm_note}" if comm_note else "")},
             "em_iters_per_s": args.steps / elapsed,
             "dense_cells_x_loci_per_s": float(N) * float(L) / (elapsed / args.steps),
+            "posterior_phase_ms": post_ms,
             "kernels_ms_note": "breakdown from a second, untimed run of the same steps with every event pair recorded; "
                                "roofline.launch_ms is from the timed region",
             "kernels_ms": {"cell_pass": ll_avg, "tile_ll": ti_ms / max(ti_n, 1), "locus_pass": lo_ms / max(lo_n, 1),

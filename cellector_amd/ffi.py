@@ -310,7 +310,10 @@ class Cellector:
         self._ck(self._lib.cellector_cell_log_likelihoods(self.h, _p(alpha), _p(beta), _p(mask), _p(ll), _p(ell), _p(nl)))
         return ll, ell, nl
 
-    def posteriors(self):
+    def posteriors(self, fetch=True):
+        if not fetch:  # (the phase on the device only: benchmarks)
+            self._ck(self._lib.cellector_posteriors(self.h, None, None, None, None))
+            return None
         n = self.n_local
         p, dp, lmaj, lmin = (np.empty(n, np.float64) for _ in range(4))
         self._ck(self._lib.cellector_posteriors(self.h, _p(p), _p(dp), _p(lmaj), _p(lmin)))
