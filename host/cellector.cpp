@@ -342,8 +342,9 @@ int main(int argc, char **argv)
         (void)cellector_device_count(&visible);
         struct stat sb;
         const uint64_t alt_bytes = stat(params.alt_mtx.c_str(), &sb) == 0 ? (uint64_t)sb.st_size : 0;
-        uint64_t want = alt_bytes < (4ull << 30) ? 1 : (alt_bytes + (4ull << 30) - 1) / (4ull << 30);  // (BASELINE cfg5: 30.7 GB -> 8)
-        if (params.alt_mtx.size() > 3 && params.alt_mtx.compare(params.alt_mtx.size() - 3, 3, ".gz") == 0) want *= 4;  // (text is ~4x the .gz)
+        const bool gz = params.alt_mtx.size() > 3 && params.alt_mtx.compare(params.alt_mtx.size() - 3, 3, ".gz") == 0;
+        const uint64_t text_bytes = alt_bytes * (gz ? 4 : 1);  // (text is ~4x the .gz)
+        const uint64_t want = text_bytes < (4ull << 30) ? 1 : (text_bytes + (4ull << 30) - 1) / (4ull << 30);  // (BASELINE cfg5: 30.7 GB -> 8)
         if (const char *e = getenv("CELLECTOR_DEVICES_AUTO_MAX")) visible = std::min(visible, atoi(e));
         const int n = (int)std::max<uint64_t>(1, std::min<uint64_t>(want, (uint64_t)std::min(visible, 16)));
         for (int i = 0; i < n; i++) devices.push_back(i);
