@@ -142,6 +142,9 @@ __global__ __launch_bounds__(64 * TB_PARTS) void k_build_tables(uint64_t L, uint
 // overflow kernels of the side stream find no room beside it and run behind it instead: cell pass 2.02 -> 2.26 ms.  Off.
 #define TILE_PF4 0
 #endif
+#ifndef TILE_PINNED
+#define TILE_PINNED 1
+#endif
 #define TILE_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
 struct __attribute__((packed, aligned(4))) tile_u4 { uint32_t x, y, z, w; };  // 16-byte load at a 4-byte aligned address
@@ -205,7 +208,9 @@ __global__ __launch_bounds__(T_THREADS, 4) void k_tile_ll(uint32_t nb, uint32_t 
     // Software pipeline over the steps t = (chunk, block) of this workgroup: the rows of step t+2 are requested in step
     // t; the slice header they need (wave-uniform: scalar loads) is requested in step t-1.  Two buffers serve the even
     // and the odd steps; a buffer is consumed and then refilled in place.
-    struct row_t { tile_u4 lo, hi; uint32_t k; const uint16_t *ptr; };  // lo: cell + entries 0..6, hi: entries 7..14
+    // lo: cell + entries 0..6, hi: entries 7..14; base = first u16 of the slice in `tiles` (wave-uniform, like k: both stay in
+    // scalar registers — the row's own address is only needed again by the rare slice with more than T_NE entries per cell)
+    struct row_t { tile_u4 lo, hi; uint32_t k; uint64_t base; };
     // slice header of step T (clamped to the last step; a workgroup at the ragged end re-reads the last block)
     const uint32_t wv_s = (uint32_t)__builtin_amdgcn_readfirstlane((int)wv);
 #define HDR_LOAD(H, T)                                                                                           \
@@ -222,9 +227,10 @@ __global__ __launch_bounds__(T_THREADS, 4) void k_tile_ll(uint32_t nb, uint32_t 
 #define ROW_LOAD(E, H)                                                                                           \
     do {                                                                                                         \
         (E).k = (H).z;                                                                                           \
-        (E).ptr = tiles + (((uint64_t)(H).y << 32) | (H).x) + lane * ((H).z + 1u);                               \
-        (E).lo = *reinterpret_cast<const tile_u4 *>((E).ptr);                                                    \
-        (E).hi = *reinterpret_cast<const tile_u4 *>((E).ptr + ((H).z > 7u ? 8u : 0u));                           \
+        (E).base = ((uint64_t)(H).y << 32) | (H).x;                                                              \
+        const uint16_t *ptr__ = tiles + (E).base + lane * ((H).z + 1u);                                          \
+        (E).lo = *reinterpret_cast<const tile_u4 *>(ptr__);                                                      \
+        (E).hi = *reinterpret_cast<const tile_u4 *>(ptr__ + ((H).z > 7u ? 8u : 0u));                             \
     } while (0)
 
     // PFD = prefetch distance in steps = number of pipeline buffers.  With four blocks per column every block of the chunk has
@@ -281,9 +287,23 @@ __global__ __launch_bounds__(T_THREADS, 4) void k_tile_ll(uint32_t nb, uint32_t 
     } while (0)
     // one level of the written-out lookup chain: request the next pair, THEN add the pair requested one level earlier (the
     // sums still run in entry order), so that four lookups of a wave are in flight instead of two
+/* (TILE_PIN: without it the compiler hoists the two adds, common to both arms, above the branch — right behind the    */
+/*  previous level's requests, which they then wait for: no lookup of the next level would be in flight meanwhile.  */
+/*  The empty asm makes the value a different one in this arm and, with its memory clobber, keeps the requests above */
+/*  it.)                                                                                                            */
+#if TILE_PINNED
+#define TILE_PIN(V)                                                                                              \
+    do {                                                                                                         \
+        if constexpr (EXPECTED) asm volatile("" : "+v"((V).x), "+v"((V).y) : : "memory");                        \
+        else asm volatile("" : "+v"(V) : : "memory");                                                            \
+    } while (0)
+#else
+#define TILE_PIN(V) do { } while (0)
+#endif
 #define TILE_LEVEL(KA, KB, PA, PB, BODY)                                                                         \
     if (K__ > (KA)) {                                                                                            \
         TILE_RD(v##KA, KA); TILE_RD(v##KB, KB);                                                                  \
+        TILE_PIN(PA); TILE_PIN(PB);                                                                              \
         TILE_ADD(PA); TILE_ADD(PB);                                                                              \
         BODY                                                                                                     \
     } else { TILE_ADD(PA); TILE_ADD(PB); }
@@ -292,7 +312,7 @@ __global__ __launch_bounds__(T_THREADS, 4) void k_tile_ll(uint32_t nb, uint32_t 
         /* 1. consume the row requested PFD steps ago: u16 number i of the row sits in half i & 1 of dword i >> 1 */ \
         const uint32_t w__[8] = {(E).lo.x, (E).lo.y, (E).lo.z, (E).lo.w, (E).hi.x, (E).hi.y, (E).hi.z, (E).hi.w}; \
         const uint32_t K__ = (uint32_t)__builtin_amdgcn_readfirstlane((int)(E).k); /* wave-uniform, odd */       \
-        const uint16_t *cur__ = (E).ptr;                                                                         \
+        const uint64_t cur_base__ = (E).base;                                                                    \
         const uint32_t cell__ = w__[0] & 0xffffu;                                                                \
         /* 2. issue the next requests: rows of step t+PFD (their header is here), header of step t+2 PFD */      \
         ROW_LOAD(E, H);                                                                                          \
@@ -305,6 +325,7 @@ __global__ __launch_bounds__(T_THREADS, 4) void k_tile_ll(uint32_t nb, uint32_t 
         TILE_RD(v0, 0);                                                                                          \
         if (K__ > 1) {                                                                                           \
             TILE_RD(v1, 1); TILE_RD(v2, 2);                                                                      \
+            TILE_PIN(v0);                                                                                        \
             TILE_ADD(v0);                                                                                        \
             TILE_LEVEL(3, 4, v1, v2,                                                                             \
             TILE_LEVEL(5, 6, v3, v4,                                                                             \
@@ -315,7 +336,7 @@ __global__ __launch_bounds__(T_THREADS, 4) void k_tile_ll(uint32_t nb, uint32_t 
                 TILE_ADD(v13); TILE_ADD(v14);                                                                    \
                 for (uint32_t k = T_NE; k < K__; k++) { /* rare: a slice with more than T_NE entries per cell */ \
                     tab_t v__;                                                                                   \
-                    TILE_LOOKUP(v__, (uint32_t)cur__[k + 1]);                                                    \
+                    TILE_LOOKUP(v__, (uint32_t)(tiles + cur_base__ + lane * (K__ + 1u))[k + 1]);                 \
                     TILE_ADD(v__);                                                                               \
                 } ))))))                                                                                         \
         } else TILE_ADD(v0);                                                                                     \
@@ -370,6 +391,7 @@ __global__ __launch_bounds__(T_THREADS, 4) void k_tile_ll(uint32_t nb, uint32_t 
   }
 #undef TILE_STEP
 #undef TILE_LEVEL
+#undef TILE_PIN
 #undef TILE_ADD
 #undef TILE_RD
 #undef TILE_LOOKUP
