@@ -30,13 +30,44 @@ tr_path = os.path.join(dst, "traffic.json")
 tr = json.load(open(tr_path)) if os.path.exists(tr_path) else {}
 dom = "k_tile_ll" if engine == 2 else "k_cell_ll"
 cand = [r for r in rows if dom in r[0] and r[3] > 1e8]
+# SQ counters of the tile kernel alone (tools/gpu_pmc.sh <tag>_sq "SQ_..." --opt side_lds=70000 > gpurun_out/<tag>_sq.log)
+sq = None
+sq_log = os.path.join(ROOT, "gpurun_out", f"{tag}_sq.log")
+if engine == 2 and os.path.exists(sq_log):
+    vals, on = {}, False
+    for ln in open(sq_log):
+        if not ln.startswith(" "):
+            on = ln.startswith("void k_tile_ll<true, 4>")
+        elif on and len(ln.split()) >= 2:
+            vals[ln.split()[0]] = float(ln.split()[1])
+    if {"SQ_BUSY_CYCLES", "SQ_LDS_IDX_ACTIVE", "SQ_LDS_BANK_CONFLICT", "SQ_WAIT_INST_ANY", "SQ_WAVE_CYCLES"} <= set(vals):
+        per_cu_cycles = vals["SQ_BUSY_CYCLES"] / 32.0  # (counted per shader engine x XCD: 32 of them)
+        lds_per_cu = vals["SQ_LDS_IDX_ACTIVE"] / 256.0
+        sq = {"source": f"profiles/{tag}_cfg4_sq_tile.csv", "kernel_cycles_per_cu": per_cu_cycles,
+              "lds_busy_frac": lds_per_cu / per_cu_cycles,
+              "bank_conflict_frac_of_lds_cycles": vals["SQ_LDS_BANK_CONFLICT"] / vals["SQ_LDS_IDX_ACTIVE"],
+              "wave_wait_frac": vals["SQ_WAIT_INST_ANY"] / vals["SQ_WAVE_CYCLES"]}
+        with open(os.path.join(dst, f"{tag}_cfg4_sq_tile.csv"), "w") as o:
+            o.write("# rocprofv3 --pmc (one pass), python3 bench.py --no-cpu-baseline --steps 3 --warmup 1 --opt side_lds=70000 (side kernels kept off "
+                    "the tile kernel's CUs: the tile kernel alone); per-launch means, summed over the chip (256 CUs)\n")
+            o.write("# k_tile_ll<true,4>, cfg4\ncounter,value\n")
+            for k in sorted(vals):
+                o.write("%s,%.4g\n" % (k, vals[k]))
+            o.write("# derived: LDS array active %.0f %% of the kernel's cycles, %.0f %% of those cycles bank conflicts; waves waiting %.0f %% of their cycles\n"
+                    % (100 * sq["lds_busy_frac"], 100 * sq["bank_conflict_frac_of_lds_cycles"], 100 * sq["wave_wait_frac"]))
 if cand:
-    tr[f"cfg4:n1:engine{engine}"] = {"kernel": dom, "hbm_bytes_per_launch": cand[0][3], "source": f"profiles/{tag}_cfg4_pmc.csv"}
+    ent = {"kernel": dom, "hbm_bytes_per_launch": cand[0][3], "source": f"profiles/{tag}_cfg4_pmc.csv"}
+    old = tr.get(f"cfg4:n1:engine{engine}", {})
+    if sq or "sq" in old:
+        ent["sq"] = sq or old["sq"]
+    tr[f"cfg4:n1:engine{engine}"] = ent
     json.dump(tr, open(tr_path, "w"), indent=1)
 if cand and engine == 2:  # the bench line was printed before this build's counters existed: carry the new figure over
     bp = os.path.join(dst, f"{tag}_bench_cfg4.json")
     b = json.load(open(bp))
     b["roofline"]["traffic"] = cand[0][3]
+    if sq:
+        b["roofline"]["lds"]["sq_counters"] = sq
     b["roofline"]["traffic_note"] = f"PMC passes of this same build (profiles/{tag}_cfg4_pmc.csv), filled in after the run"
     json.dump(b, open(bp, "w"), indent=1)
 print("wrote profiles for", tag, "dominant kernel traffic:", cand[0][3] if cand else None)
