@@ -122,6 +122,29 @@ cellector_status dev_sort_pairs_u32_u64(cellector_ctx *c, uint32_t *keys_in, uin
     return CELLECTOR_OK;
 }
 
+// The same sort with the caller's two buffer pairs as the sort's ping-pong storage (both get overwritten; on return *keys /
+// *vals point at the sorted data, *keys_alt / *vals_alt at the other buffers).  The form above must leave its input alone
+// and therefore asks for a second pair of buffers as temporary storage: 24 GB at 2e9 pairs — fresh VRAM whenever the caching
+// layer has no block of that size, 0.7-1.5 s of mapping in one run out of three of the 1M x 200k ingest.
+cellector_status dev_sort_pairs_u32_u64_inplace(cellector_ctx *c, uint32_t **keys, uint32_t **keys_alt, uint64_t **vals,
+                                                uint64_t **vals_alt, uint64_t n, int end_bit)
+{
+    if (n == 0) return CELLECTOR_OK;
+    rocprim::double_buffer<uint32_t> kb(*keys, *keys_alt);
+    rocprim::double_buffer<uint64_t> vb(*vals, *vals_alt);
+    size_t tmp_bytes = 0;
+    HIPCHK(c, rocprim::radix_sort_pairs(nullptr, tmp_bytes, kb, vb, (size_t)n, 0u, (unsigned)end_bit, c->stream));
+    char *tmp = nullptr;
+    CHK(dev_alloc(c, &tmp, tmp_bytes));
+    hipError_t e = rocprim::radix_sort_pairs(tmp, tmp_bytes, kb, vb, (size_t)n, 0u, (unsigned)end_bit, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    dev_free(tmp);
+    HIPCHK(c, e);
+    *keys = kb.current(); *keys_alt = kb.alternate();
+    *vals = vb.current(); *vals_alt = vb.alternate();
+    return CELLECTOR_OK;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // pass 1 (load_data.rs:265-270) + allele totals: per locus, #cells with ref>0, #cells with alt>0, Σref, Σalt,
 // #entries, as f64 (exact: integers < 2^53) into the PASS1 exchange planes.
@@ -448,8 +471,10 @@ cellector_status ingest_build(cellector_ctx *c, uint64_t min_alt, uint64_t min_r
     lap("CSC fill");
     int bits = 1;
     while (bits < 32 && (1ull << bits) < nloc) bits++;
-    CHK(dev_sort_pairs_u32_u64(c, key, key_o, val, c->csr_ent, c->nnz, bits));
-    hipLaunchKernelGGL(k_row_ptr_from_keys, dim3(g1(c->nnz + 1)), dim3(IB), 0, c->stream, c->nnz, key_o, nloc, c->csr_ptr);
+    // (the sorted entries end in one of the two value buffers: that one becomes the CSR, the other is freed below)
+    CHK(dev_sort_pairs_u32_u64_inplace(c, &key, &key_o, &val, &c->csr_ent, c->nnz, bits));  // (key / val: sorted now)
+    std::swap(val, c->csr_ent);
+    hipLaunchKernelGGL(k_row_ptr_from_keys, dim3(g1(c->nnz + 1)), dim3(IB), 0, c->stream, c->nnz, key, nloc, c->csr_ptr);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(c->stream));
     lap("sort by cell");

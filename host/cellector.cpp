@@ -23,6 +23,7 @@
 #include <optional>
 #include <chrono>
 #include <string>
+#include <string_view>
 #include <thread>
 #include <unordered_map>
 #include <vector>
@@ -31,12 +32,12 @@
 
 namespace {
 
+constexpr int EXIT_PANIC = 101;  // what a Rust panic gives the caller (cellector_pipeline.py checks != 0 only)
 [[noreturn]] void die(int code, const std::string &msg)
 {
     fprintf(stderr, "%s\n", msg.c_str());
     exit(code);
 }
-constexpr int EXIT_PANIC = 101;  // what a Rust panic gives the caller (cellector_pipeline.py checks != 0 only)
 
 // ---- Rust `{}` formatting of f64: shortest round-trip digits, never scientific --------
 std::string fmt(double v)
@@ -113,6 +114,40 @@ struct Lines {
         return any;
     }
 };
+
+// the bytes of a (possibly gzipped) text file
+std::string read_whole(const std::string &path)
+{
+    gzFile gz = gzopen(path.c_str(), "rb");  // transparent for plain files
+    if (!gz) die(EXIT_PANIC, "couldn't open file " + path);
+    gzbuffer(gz, 1 << 20);
+    std::string out;
+    std::vector<char> buf(4 << 20);
+    for (;;) {
+        const int n = gzread(gz, buf.data(), (unsigned)buf.size());
+        if (n <= 0) break;
+        out.append(buf.data(), (size_t)n);
+    }
+    gzclose(gz);
+    return out;
+}
+// BufRead::lines() over a buffer: "\n" ends a line, a "\r" in front of it is dropped, a last line needs no terminator
+std::vector<std::string_view> split_lines(const std::string &text)
+{
+    std::vector<std::string_view> out;
+    out.reserve(text.size() / 16 + 1);
+    size_t b = 0;
+    while (b < text.size()) {
+        size_t e = text.find('\n', b);
+        const size_t next = e == std::string::npos ? text.size() : e + 1;
+        if (e == std::string::npos) e = text.size();
+        size_t len = e - b;
+        if (len && e < text.size() && text[e] == '\n' && text[e - 1] == '\r') len--;  // (only a terminated line loses its "\r")
+        out.emplace_back(text.data() + b, len);
+        b = next;
+    }
+    return out;
+}
 
 std::vector<std::string> split(const std::string &s, char sep)
 {
@@ -298,27 +333,44 @@ int main(int argc, char **argv)
     // create_output_dir (load_data.rs:66-71): non-recursive mkdir, failure ignored (quirk Q13)
     (void)mkdir(params.output_directory.c_str(), 0777);
 
-    // load_barcodes (load_data.rs:73-83)
-    std::vector<std::string> barcodes;
-    std::unordered_map<std::string, size_t> barcode_to_cell;
+    // load_barcodes (load_data.rs:73-83): the lines of the file; barcode -> cell index for the ground truth, a later
+    // duplicate overwriting an earlier one (HashMap::insert).  The file is read whole and the table is a flat open-addressing
+    // one over views into it — a std::unordered_map<std::string, size_t> of a million barcodes was 0.3-0.6 s of node
+    // allocations.
+    std::string barcode_text = read_whole(params.barcodes);
+    std::vector<std::string_view> barcodes = split_lines(barcode_text);
+    std::vector<uint32_t> bc_slot;  // line index + 1 of the LAST line with that barcode, 0 = empty
+    size_t n_distinct = 0;
     {
-        Lines in(params.barcodes);
-        std::string line;
-        while (in.next(line)) {
-            barcode_to_cell[line] = barcodes.size();
-            barcodes.push_back(line);
+        size_t cap = 16;
+        while (cap < 2 * barcodes.size() + 2) cap <<= 1;
+        bc_slot.assign(cap, 0u);
+        if (barcodes.size() >= 0xffffffffull) die(EXIT_PANIC, "too many barcodes");
+        for (size_t i = 0; i < barcodes.size(); i++) {
+            size_t h = std::hash<std::string_view>{}(barcodes[i]) & (cap - 1);
+            for (;; h = (h + 1) & (cap - 1)) {
+                if (!bc_slot[h]) { bc_slot[h] = (uint32_t)i + 1; n_distinct++; break; }
+                if (barcodes[bc_slot[h] - 1] == barcodes[i]) { bc_slot[h] = (uint32_t)i + 1; break; }
+            }
         }
     }
-    // load_ground_truth (load_data.rs:85-107)
-    std::vector<std::string> ground_truth(barcode_to_cell.size(), "na");
+    auto barcode_to_cell = [&](std::string_view key) -> size_t {  // SIZE_MAX: not a barcode
+        const size_t cap = bc_slot.size();
+        for (size_t h = std::hash<std::string_view>{}(key) & (cap - 1);; h = (h + 1) & (cap - 1)) {
+            if (!bc_slot[h]) return SIZE_MAX;
+            if (barcodes[bc_slot[h] - 1] == key) return bc_slot[h] - 1;
+        }
+    };
+    // load_ground_truth (load_data.rs:85-107): one label per DISTINCT barcode (the vector has the map's length)
+    std::vector<std::string> ground_truth(n_distinct, "na");
     if (params.ground_truth) {
         Lines in(*params.ground_truth);
         std::string line;
         while (in.next(line)) {
             auto cols = split(line, '\t');
             if (cols.size() != 2) die(EXIT_PANIC, "Invalid line format: " + line + "\nThe correct format is: barcode\tassignment");
-            auto it = barcode_to_cell.find(cols[0]);
-            if (it != barcode_to_cell.end() && it->second < ground_truth.size()) ground_truth[it->second] = cols[1];
+            const size_t cell = barcode_to_cell(cols[0]);
+            if (cell != SIZE_MAX && cell < ground_truth.size()) ground_truth[cell] = cols[1];
         }
     }
 
