@@ -169,6 +169,13 @@ void dev_cache_free(void *p)
     (void)hipFree(p);
 }
 
+// a block nobody has used yet goes to the free list as it is (no device synchronisation needed)
+void dev_cache_park(void *p, size_t bytes, int device)
+{
+    std::lock_guard<std::mutex> lk(g_cache_mu);
+    g_cache_free.push_back(DevBlock{p, bytes, device});
+}
+
 void dev_cache_trim()
 {
     std::vector<DevBlock> blocks;

@@ -217,6 +217,7 @@ cellector_status ctx_fail(const cellector_ctx *c, cellector_status s, const char
 hipError_t dev_cache_malloc(void **p, size_t bytes);
 void dev_cache_free(void *p);
 void dev_cache_trim();
+void dev_cache_park(void *p, size_t bytes, int device);  // a fresh, unused hipMalloc block for later requests of its size
 
 template <typename T>
 static inline cellector_status dev_alloc(cellector_ctx *c, T **p, uint64_t n)
