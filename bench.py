@@ -143,14 +143,23 @@ def main():
     comm_note = None
     if lib_comm:
         ok, why = 1, ""
-        try:
-            uid = torch.zeros(128, dtype=torch.uint8, device=dev)
-            if rank == 0:
-                uid.copy_(torch.frombuffer(bytearray(ffi.comm_unique_id()), dtype=torch.uint8))
-            dist.broadcast(uid, 0)
-            g.comm_init_rank(bytes(uid.cpu().numpy().tobytes()), world, rank)
-        except Exception as e:  # noqa: BLE001
-            ok, why = 0, str(e)
+        # (every rank takes part in the broadcast whatever happened on rank 0: byte 128 says whether the id is valid)
+        uid = torch.zeros(129, dtype=torch.uint8, device=dev)
+        if rank == 0:
+            try:
+                raw = bytearray(ffi.comm_unique_id()) + bytearray([1])
+                uid.copy_(torch.frombuffer(raw, dtype=torch.uint8))
+            except Exception as e:  # noqa: BLE001
+                ok, why = 0, str(e)
+        dist.broadcast(uid, 0)
+        uid_h = uid.cpu().numpy()
+        if int(uid_h[128]) != 1:
+            ok, why = 0, why or "rank 0 could not make a communicator id"
+        else:
+            try:
+                g.comm_init_rank(bytes(uid_h[:128].tobytes()), world, rank)
+            except Exception as e:  # noqa: BLE001
+                ok, why = 0, str(e)
         flag = torch.tensor([float(ok)], dtype=torch.float64, device=dev)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if flag.item() < 1.0:
