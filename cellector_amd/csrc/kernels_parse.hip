@@ -1066,7 +1066,7 @@ cellector_status ingest_stage_mtx_device(cellector_ctx *c, MtxInput *in, cellect
             const char *env = getenv("CELLECTOR_PREMAP");
             const bool all = c->cell_begin == 0 && c->cell_end >= c->total_cells;
             const uint64_t hint = std::min<uint64_t>(in->nnz_hint, (fa.size - off_a) / 6);  // (a line has at least 6 bytes)
-            if (win_a && all && hint >= (1ull << 26) && (!env || atoi(env) != 0)) {
+            if (win_a && all && !c->ingest_all_cells && hint >= (1ull << 26) && (!env || atoi(env) != 0)) {  // (not for a multi-device ctx's parser: its shards build smaller matrices)
                 const int dev = c->device;
                 premap = std::thread([dev, hint] {
                     if (hipSetDevice(dev) != hipSuccess) return;
