@@ -345,7 +345,7 @@ cellector_status cellector_set_option(cellector_ctx *c, const char *key, int64_t
     else if (!strcmp(key, "sharded_select")) c->sharded_select = v < 0 ? -1 : (v != 0);
     else if (!strcmp(key, "parse_window")) c->parse_window_opt = v < 0 ? 0 : v;
     else if (!strcmp(key, "tile_groups")) {
-        if (v < 0 || v > 64 || v % 8) return ctx_fail(c, CELLECTOR_EINVAL, "tile_groups must be 0 (automatic) or a multiple of 8 up to 64");
+        if (v < 0 || v > 64) return ctx_fail(c, CELLECTOR_EINVAL, "tile_groups must be 0 (automatic) or 1..64");
         c->tile_groups_opt = (int)v;
     }
     else if (!strcmp(key, "locus_mode")) {

@@ -40,7 +40,7 @@
 static_assert(T_BC == T_ROWS_PER_TILE, "cellector_engine_info derives the lookup count from this");
 #define T_SB_MAX 4      // cell blocks per workgroup sharing one staged table (2 or 4: chosen per launch)
 #define T_GROUPS_MAX 64 // upper bound of the chunk groups of a launch
-#define T_GROUPS 8      // chunk groups (== XCDs: the workgroups of a group run on one XCD and share its L2)
+#define T_GROUPS 8      // chunk groups beyond this many are charged for their partial sums (tiled_build's cost model)
 #define T_NE 15         // entries per cell of a slice held in registers (two 16-byte loads); longer slices: slow path
 // A u16 entry = n-1 << 14 | locus slot << 4 | code: log-pmf at table[slot * T_LROW + code], expected term at
 // table[slot * T_LROW + T_NCODE + (n-1)].
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(T_THREADS, 4) void k_tile_ll(uint32_t nb, uint32_t 
                                                           double *__restrict__ part_ll, double *__restrict__ part_ell)
 {
     // PERSISTENT workgroups, one per CU (the LDS footprint allows no second one): a workgroup belongs to one group of locus
-    // chunks (= one XCD, see below) and keeps fetching columns of T_SB consecutive 1024-cell blocks from the group's
+    // chunks and keeps fetching columns of T_SB consecutive 1024-cell blocks from the group's
     // counter until none is left.  A grid of short-lived workgroups instead leaves a CU idle whenever the next one cannot
     // start because waves of the small overflow kernels running beside this one still hold registers there (measured:
     // 2.2 ms alone, 2.7 ms next to them).
@@ -174,8 +174,8 @@ __global__ __launch_bounds__(T_THREADS, 4) void k_tile_ll(uint32_t nb, uint32_t 
     __shared__ tab_t s_acc[T_SB * T_BC];  // per-cell sums of the workgroup's blocks
     __shared__ uint32_t s_col;
     const uint32_t tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
-    // group = linear block id mod groups: with a multiple of 8 groups all workgroups of a group land on the same XCD
-    // (round-robin dispatch), whose L2 then serves the group's table reads
+    // group = linear block id mod groups (the workgroups of a group walk its chunks in step: each XCD's L2 fetches a table
+    // chunk once, whatever the number of groups)
     const uint32_t g = blockIdx.x % groups;
     const uint32_t j0 = g * cpg, j1 = min(nj, j0 + cpg);
     if (j0 >= j1) return;
@@ -1613,29 +1613,31 @@ cellector_status tiled_build(cellector_ctx *c)
     c->t_nj = (uint32_t)((L + T_BLU - 1) / T_BLU);
     if (c->t_nb == 0) c->t_nb = 1;
     if (c->t_nj == 0) c->t_nj = 1;
-    // Chunk groups: a multiple of the 8 XCDs (workgroup i runs on XCD i mod 8, so a group's workgroups share one L2).  The
-    // tile kernel runs one persistent workgroup per CU, each bound to a group and fetching columns of T_SB_MAX cell
-    // blocks; more groups mean shorter turns per column (better balance when there are few columns per workgroup) at the
-    // price of one more partial sum per cell and group.
+    // Chunk groups.  The tile kernel runs one persistent workgroup per CU, each bound to a group of locus chunks and fetching
+    // columns of T_SB_MAX cell blocks from the group's counter; a cell gets one partial sum per group.  Every workgroup of a
+    // group walks the group's chunks once per column it fetches, so the kernel takes about rounds(g) x (chunks(g) + 3)
+    // chunk-steps with rounds = ceil(columns / workgroups per group) — a column costs its chunks plus a fixed part
+    // (accumulators cleared and written out as partial sums), put at three chunk-steps.  Any count from 1 up is taken, the one
+    // with the shortest makespan wins (ties: fewer groups), charging 3 % per 8 groups beyond 8 for the additional partial
+    // sums (16 bytes more per cell and pass written by the tile kernel and read by the finalize).  Measured (ms per EM
+    // iteration): 10^6 cells x 200k loci (245 columns, 313 chunks): 1 group 2.33, 2: 2.34, 4: 2.36, 7: 2.43, 8: 2.44, 32:
+    // 2.59 — with one group every workgroup does one column over all chunks: no ragged last round, no partial sums to add
+    // up; 200k cells x 100k loci (49 columns, 157 chunks): 5 groups 0.394 (245 workgroups, one round), 8: 0.430 (two rounds,
+    // the second half empty), 2: 0.48, 1: 0.73 (49 CUs busy).  Groups used to be multiples of 8 so that a group's workgroups
+    // shared an XCD's L2 for the table reads (workgroup i runs on XCD i mod 8): the figures above show no such need — the
+    // workgroups of a group walk the chunks in step, a table chunk is fetched once per XCD either way.
     {
         int ncu = 256;
         (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, c->device);
         const uint64_t cols = (c->t_nb + T_SB_MAX - 1) / T_SB_MAX;
-        // every workgroup of a group walks the group's chunks once per column it fetches: the kernel takes about
-        // rounds(g) x (chunks(g) + 3) chunk-steps with rounds = ceil(columns / workgroups per group) — a column costs its
-        // chunks plus a fixed part (accumulators cleared and written out as partial sums), put at three chunk-steps.
-        // Take the multiple of 8 with the shortest makespan, charging 3 % per extra 8 groups for the additional partial
-        // sums (16 bytes more per cell and pass written by the tile kernel and read by the finalize).  Few groups win on
-        // big matrices (measured: 8 groups 2.48 ms per iteration at 10^6 cells, 32 groups 2.59; 200k cells: 8 groups 0.435,
-        // 24 groups 0.447), more groups only where 8 leave CUs without a column (50k cells: 13 columns).
-        uint64_t groups = T_GROUPS;
+        uint64_t groups = 1;
         double best = 1e300;
-        for (uint64_t g = T_GROUPS; g <= T_GROUPS_MAX && g <= (uint64_t)c->t_nj; g += T_GROUPS) {
+        for (uint64_t g = 1; g <= T_GROUPS_MAX && g <= (uint64_t)c->t_nj; g++) {
             uint64_t per = (uint64_t)ncu / g;
             if (per < 1) per = 1;
             if (per > cols) per = cols;
             const uint64_t rounds = (cols + per - 1) / per, chunks = ((uint64_t)c->t_nj + g - 1) / g;
-            const double cost = (double)(rounds * (chunks + 3)) * (1.0 + 0.03 * (double)(g / T_GROUPS - 1));
+            const double cost = (double)(rounds * (chunks + 3)) * (1.0 + 0.03 * (g > T_GROUPS ? (double)(g - T_GROUPS) / T_GROUPS : 0.0));
             if (cost < best) { best = cost; groups = g; }
         }
         if (c->tile_groups_opt > 0) groups = (uint64_t)c->tile_groups_opt;  // (A/B runs)

@@ -93,7 +93,7 @@ cellector_status cellector_set_stream(cellector_ctx *ctx, void *hip_stream);
  * within rounding: the summation order inside a cell's overflow entries differs; "ovf_deep_wide", default 1: that kernel
  * gives 16 lanes to a row, 0 = a thread per row — A/B),
  * "tile_groups" (engine 2, default 0: the number of locus-chunk groups of the tile kernel is chosen per matrix;
- * a multiple of 8 up to 64 forces it — set before ingest; results may differ in the last bit),
+ * 1..64 forces it — set before ingest; results may differ in the last bit),
  * "parse_window" (default 0: a text file of 1 GB or more is uploaded and tokenised in 256 MB windows, a smaller
  * one whole; a positive value forces windows of that many bytes — tests; lines of a windowed file may be 1 MB long),
  * "synth_continue_pct" (default 30: cellector_ingest_synthetic draws an entry's total as 1 + Geometric(0.7), vartrix-like
