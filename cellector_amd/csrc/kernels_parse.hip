@@ -1065,15 +1065,18 @@ cellector_status ingest_stage_mtx_device(cellector_ctx *c, MtxInput *in, cellect
         {
             const char *env = getenv("CELLECTOR_PREMAP");
             const bool all = c->cell_begin == 0 && c->cell_end >= c->total_cells;
-            const uint64_t hint = std::min<uint64_t>(in->nnz_hint, (fa.size - off_a) / 6);  // (a line has at least 6 bytes)
+            const uint64_t hint = in->nnz_hint <= (fa.size - off_a) / 6 ? in->nnz_hint : 0;  // (a line has at least 6 bytes: else the header lies)
             if (win_a && all && !c->ingest_all_cells && hint >= (1ull << 26) && (!env || atoi(env) != 0)) {  // (not for a multi-device ctx's parser: its shards build smaller matrices)
                 const int dev = c->device;
                 premap = std::thread([dev, hint] {
                     if (hipSetDevice(dev) != hipSuccess) return;
                     // (a little more than 8 bytes per entry: the 4-byte token arrays, asked for meanwhile, must not match
                     //  these blocks — the caching layer hands out blocks of up to twice the request)
-                    const size_t bytes = (size_t)hint * 8 + (1u << 16);
-                    for (int k = 0; k < 3; k++) {
+                    // in the order they are asked for: the ref file's count tokens (4 B per entry, as parse_windowed sizes
+                    // them), the two 16-bit count arrays of the staged entries, then the CSC / CSR build's three arrays
+                    const size_t sizes[6] = {((size_t)hint + 16) * 4, (size_t)hint * 2 + 4096, (size_t)hint * 2 + 4096,
+                                             (size_t)hint * 8 + (1u << 16), (size_t)hint * 8 + (1u << 16), (size_t)hint * 8 + (1u << 16)};
+                    for (size_t bytes : sizes) {
                         void *p = nullptr;
                         if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); return; }
                         dev_cache_park(p, bytes, dev);
