@@ -114,6 +114,45 @@ def _run(d, host_bin, ob, Cellector, synth):
         assert filecmp.cmp(os.path.join(out, name), os.path.join(out2, name), shallow=False), name
     assert r.stdout == r2.stdout
     shutil.rmtree(out2)
+    # ---- the same run sharded over four logical shards of the GPU, the text ingest in its split form (every shard tokenises
+    # a byte range of both files and the entries are routed to their owners: what a multi-GPU node does from three devices
+    # on): the sharded ingest, scoring loop, posteriors and tallies at BASELINE size.  Integer results must be identical;
+    # per-cell sums may differ in the last bits (a shard picks its own number of chunk groups).
+    out3 = os.path.join(d, "out3")
+    cmd3 = list(cmd) + ["--devices", "0,0,0,0"]
+    cmd3[cmd3.index(out)] = out3
+    t0 = time.time()
+    r3 = subprocess.run(cmd3, capture_output=True, text=True, timeout=600, env=dict(os.environ, CELLECTOR_MULTI_SPLIT="1"))
+    assert r3.returncode == 0, r3.stderr[-2000:]
+    print(f"host/cellector --devices 0,0,0,0 (split ingest) on 1M x 200k text: {time.time() - t0:.1f} s wall")
+    assert sorted(os.listdir(out3)) == sorted(os.listdir(out))
+    assert filecmp.cmp(os.path.join(out, "cellector.vcf"), os.path.join(out3, "cellector.vcf"), shallow=False)
+    det1 = [ln for ln in r.stdout.splitlines() if ln.startswith("detected ")]
+    det3 = [ln for ln in r3.stdout.splitlines() if ln.startswith("detected ")]
+    assert det1 == det3 and len(det1) >= 2
+    for name in sorted(os.listdir(out)):
+        if name.endswith("_threshold.tsv"):
+            a, b = float(open(os.path.join(out, name)).read()), float(open(os.path.join(out3, name)).read())
+            assert abs(a - b) <= 1e-12 * abs(a), name
+        elif name.startswith("iteration_") and "locus" not in name:
+            x = _read_tsv(os.path.join(out, name))
+            y = _read_tsv(os.path.join(out3, name))
+            assert (x["barcode"] == y["barcode"]).all() and (x["assignment"] == y["assignment"]).all(), name
+            assert np.array_equal(x["num_loci_used"].to_numpy(), y["num_loci_used"].to_numpy()), name
+            for col in ("log_likelihood", "expected_log_likelihood"):
+                u, v = x[col].to_numpy(np.float64), y[col].to_numpy(np.float64)
+                assert np.max(np.abs(u - v) / np.maximum(1.0, np.abs(u))) < 1e-12, (name, col)
+    x = _read_tsv(os.path.join(out, "cellector_assignments.tsv"))
+    y = _read_tsv(os.path.join(out3, "cellector_assignments.tsv"))
+    for col in ("barcode", "posterior_assignment", "anomally_assignment", "ground_truth_assignment"):
+        assert (x[col] == y[col]).all(), col
+    assert np.array_equal(x["loci_used"].to_numpy(), y["loci_used"].to_numpy())
+    assert np.max(np.abs(x["posterior_assign_qual"].to_numpy(np.int64) - y["posterior_assign_qual"].to_numpy(np.int64))) <= 1
+    for col in ("log_likelihood_loci_normalized", "majority_log_likelihood", "minority_log_likelihood"):
+        u, v = x[col].to_numpy(np.float64), y[col].to_numpy(np.float64)
+        assert np.max(np.abs(u - v) / np.maximum(1.0, np.abs(u))) < 1e-12, col
+    del x, y
+    shutil.rmtree(out3)
     os.remove(alt); os.remove(ref)  # (61 GB of host memory back before the checks allocate theirs)
 
     # ---- the matrix for the checks: generator -> CSR on the device (same seed; never saw the text)
