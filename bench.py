@@ -68,7 +68,8 @@ def roofline(args, kernel, launch_ms, units, b_alg, achieved, traffic, traffic_s
     t = launch_ms * 1e-3
     out = {"kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
            "frac_is": "algorithmic bytes (SURVEY 8(d): 8 B per entry + row pointers + outputs + alpha/beta) / launch time / 8 TB/s"
-                      " = rate of reference-equivalent work, NOT an HBM utilisation",
+                      " = rate of reference-equivalent work, NOT an HBM utilisation (it can exceed 1: the kernel reads the same"
+                      " entries from a 16-bit tiled layout of ~2.7 B each, see hbm_frac_measured / hbm_frac_layout and bound)",
            "algorithmic_bytes_per_launch": int(b_alg), "launch_ms": launch_ms, "entries_per_launch": int(units),
            "traffic": traffic,
            "traffic_is": ("HBM bytes per launch from rocprofv3 PMC passes of this command, committed as " + str(traffic_src)
