@@ -338,8 +338,15 @@ cellector_status cellector_set_option(cellector_ctx *c, const char *key, int64_t
     else if (!strcmp(key, "ovf_deep_wide")) c->ovf_deep_wide = v != 0;
     else if (!strcmp(key, "ovf_deep")) {
         if (v < -1 || v > 1) return ctx_fail(c, CELLECTOR_EINVAL, "ovf_deep must be -1 (automatic), 0 or 1");
+        if (c->tiled_ready && v >= 0 && c->ovf_deep != (v != 0))
+            return ctx_fail(c, CELLECTOR_EINVAL, "ovf_deep decides which overflow layouts the ingest builds: set it before the ingest");
         c->ovf_deep_opt = (int)v;
-        if (c->tiled_ready && v >= 0) c->ovf_deep = v != 0;
+    }
+    else if (!strcmp(key, "t2")) {
+        if (v < -1 || v > 1) return ctx_fail(c, CELLECTOR_EINVAL, "t2 must be -1 (automatic), 0 or 1");
+        if (c->tiled_ready && v >= 0 && c->t2 != (v != 0))
+            return ctx_fail(c, CELLECTOR_EINVAL, "t2 decides which overflow layouts the ingest builds: set it before the ingest");
+        c->t2_opt = (int)v;
     }
     else if (!strcmp(key, "norm_zero")) c->norm_zero = v != 0;
     else if (!strcmp(key, "sharded_select")) c->sharded_select = v < 0 ? -1 : (v != 0);

@@ -142,6 +142,19 @@ struct cellector_ctx {
     uint64_t ovf_n_tier[2] = {0, 0};
     double *ovf_tier_val = nullptr;  // [2][ovf_n_tier[1]] per pass: log-pmf / expected term of the tier-1 entries (k_ovf_listed_values)
     uint32_t *ovf_nmask = nullptr;   // [L] which alt+ref totals (4..17) occur among the locus' overflow entries
+    // tier 2 (kernels_tiled.hip, k_t2_tables): the overflow entries with totals 5..8 are table-driven as well
+    int t2_opt = -1;                 // option "t2": -1 = decided per matrix (tiled_build: on unless the matrix is ovf_deep), 0 / 1 = forced
+    bool t2 = false;
+    uint32_t *hist_all2 = nullptr;   // [L][32] tier-2 entries per (locus, pair), all cells of the shard (static)
+    uint32_t *t2_plist = nullptr, *t2_slist = nullptr;  // the pairs (locus << 5 | pair) / table sectors (locus << 3 | sector) that occur, locus order (static)
+    uint32_t t2_np = 0, t2_ns = 0;
+    uint32_t *t2_pmask = nullptr;    // [L] bit c2: the pair occurs at the locus (static)
+    uint32_t *cnt2 = nullptr;        // [L][32] ... of the cells of the new exclusion set (k_t2_minority; cleared by k_locus_finalize)
+    double *tab2 = nullptr;          // [L][48] per pass: log-pmfs of the pairs that occur + expected terms, six 64-byte sectors per locus
+    uint64_t *ovx_ptr = nullptr, *ovx_ent = nullptr;  // by-locus CSC of the overflow entries outside tier 2 (totals 0 and above 8)
+    uint32_t *ovx_locus = nullptr;   // [ovx_n] their compact locus index
+    double *ovx_lp = nullptr;        // [ovx_n] the EM pass' log-pmfs of those entries (k_ovx_values -> k_locus_finalize)
+    uint64_t ovx_n = 0;
     uint64_t *c4_ptr = nullptr;      // [L+1] compact CSC of regular entries
     uint32_t *c4_ent = nullptr;      // 32-bit entries cell_local | code << 28, or 24-bit cell | code << 20 (c4_bits)
     int c4_bits = 32;

@@ -32,8 +32,12 @@
 
 #define T_K 4           // entries with 1 <= alt+ref <= T_K are "regular": log-pmf and expected term come from tables
 #define T_NCODE 14      // (alt, ref) combinations with 1 <= n <= T_K: K(K+3)/2
+#ifndef T_LROW
 #define T_LROW 18       // table doubles per locus: the T_NCODE log-pmfs, then the T_K expected terms
+#endif
+#ifndef T_BL
 #define T_BL 640        // locus slots per chunk (the table is T_BL * T_LROW * 8 B = 90 KB of LDS); the last slot is all zeros
+#endif
 #define T_BLU (T_BL - 1)  // loci per chunk
 #define T_BC 1024       // cells per block == threads per workgroup
 #define T_THREADS 1024
@@ -422,6 +426,22 @@ __device__ __forceinline__ T group16_sum(T v)
 #define OV_NE 17  // expected terms E(n) tabulated for n = 4..17
 #define OV_FAST_N DM_CHUNK  // the cell side's fast kernel takes totals up to this (99 % of the overflow entries)
 
+// tier 2 (see k_t2_tables below)
+#define T2_NMIN 5u
+#define T2_NMAX 8u
+#define T2_NCODE 30    // (alt, ref) pairs with 5 <= alt+ref <= 8; code = n(n+1)/2 - 15 + ref
+#define T2_CSTRIDE 32  // u32 counters per locus (hist_all2, cnt2)
+#define T2_ROW 48      // table doubles per locus
+static_assert(T2_NMAX == (unsigned)OV_FAST_N, "the tier lists take the totals above tier 2");
+__device__ __forceinline__ bool t2_total(uint32_t n) { return n - T2_NMIN <= T2_NMAX - T2_NMIN; }
+__device__ __forceinline__ uint32_t t2_code(uint32_t n, uint32_t r) { return n * (n + 1u) / 2u - 15u + r; }
+// position of the pair's log-pmf in the locus' table row; its sector's first double is E(n)
+__device__ __forceinline__ uint32_t t2_pos(uint32_t n, uint32_t r)
+{
+    const uint32_t hi = r >= 7u ? 1u : 0u;
+    return ((n - T2_NMIN) + (n == 8u ? 1u : 0u) + hi) * 8u + 1u + (hi ? r - 7u : r);
+}
+
 // rare cases kept out of line so that the common path stays small
 __device__ __noinline__ double ov_slow_log_pmf(const double *lf, double alpha, double beta, uint32_t a, uint32_t r)
 {
@@ -493,7 +513,7 @@ __global__ __launch_bounds__(256) void k_ovf_tables_e(uint64_t L, const double2 
     if (l >= L) return;
     const uint32_t i = (uint32_t)(idx & 15u);
     if (i == 15u) {  // (a masked locus carries its negative alpha along: the cell side tests that)
-        *reinterpret_cast<double2 *>(etab + l * OV_REC) = ab[l];
+        if (etab) *reinterpret_cast<double2 *>(etab + l * OV_REC) = ab[l];
         return;
     }
     if (i > (uint32_t)OV_NE - 4u || !((nmask[l] >> i) & 1u)) return;
@@ -501,7 +521,7 @@ __global__ __launch_bounds__(256) void k_ovf_tables_e(uint64_t L, const double2 
     if (!(p.x >= 0.0)) return;
     const double e = ov_expected_rec(p.x, p.y, 4u + i);
     otab[l * OV_ROW + OV_EOFF + i] = e;
-    if (i >= 1 && i <= 4) etab[l * OV_REC + 2 + (i - 1)] = e;
+    if (etab && i >= 1 && i <= 4) etab[l * OV_REC + 2 + (i - 1)] = e;
 }
 
 // The overflow entries' log-pmfs in by-locus order for the locus finalize, shallow-coverage form: a thread per entry
@@ -635,7 +655,8 @@ __global__ __launch_bounds__(256) void k_ovf_cell_direct(
 // 64-byte record per locus in the EM pass.  The per-lane sums are added by a fixed-shape butterfly (deterministic).
 // (Measured and dropped: one launch per locus range whose records fit an L2 — 9.3 -> 11-14 ms: the kernel is bound by its
 // arithmetic, not by the gathers.)
-template <bool EXPECTED>
+// REST_ONLY (a tier-2 shard): the entries of tier 2 are k_t2_cell's; this kernel skips them and ADDS to that kernel's sums.
+template <bool EXPECTED, bool REST_ONLY>
 __global__ __launch_bounds__(256) void k_ovf_cell_wide(uint64_t n_rows, const uint64_t *__restrict__ ovf_ptr,
                                                        const uint64_t *__restrict__ ovf_ent, const double2 *__restrict__ ab,
                                                        const double *__restrict__ lf, const double *__restrict__ etab,
@@ -660,7 +681,7 @@ __global__ __launch_bounds__(256) void k_ovf_cell_wide(uint64_t n_rows, const ui
             else if (n > (uint32_t)OV_FAST_N && n <= (uint32_t)OV_NE) ev = otab[(uint64_t)l * OV_ROW + OV_EOFF + (n - 4)];
         }
         // masked locus: no PMFData (main.rs:556); 0/0 entry: exactly zero (Q14); totals above OV_NE: the generic list
-        if (!(p.x >= 0.0) || n == 0 || n > (uint32_t)OV_NE) continue;
+        if (!(p.x >= 0.0) || n == 0 || n > (uint32_t)OV_NE || (REST_ONLY && t2_total(n))) continue;
         double lp;
         if (p.x + p.y < 1e17) {
             double num = 1.0, den = 1.0, fa = p.x, fb = p.y, fab = p.x + p.y;
@@ -682,9 +703,175 @@ __global__ __launch_bounds__(256) void k_ovf_cell_wide(uint64_t n_rows, const ui
     s = group16_sum(s);
     if (EXPECTED) e = group16_sum(e);
     if (in && j == 0) {
-        o_ll[row] = s;
-        if (EXPECTED) o_ell[row] = e;
+        o_ll[row] = REST_ONLY ? o_ll[row] + s : s;
+        if (EXPECTED) o_ell[row] = REST_ONLY ? o_ell[row] + e : e;
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// tier 2: the overflow entries with 5 <= alt+ref <= 8 (99 % of them at vartrix-like coverage) are table-driven as well.
+// Under one (alpha_l, beta_l) their log-pmf depends on (alt, ref) only and a locus carries few distinct pairs, so a pass
+// evaluates every (locus, pair) that occurs in the shard ONCE (k_t2_tables: 30 pairs + 4 expected terms per locus at most, a
+// static histogram says which occur) into a table in global memory, and both consumers read it:
+//   cell side   k_t2_cell: a thread per cell row, four entries' lookups in flight — no arithmetic, a 64-byte sector per entry
+//               (it used to evaluate a log of a product ratio per entry with one wave per SIMD beside the tile kernel: 1.2 ms
+//               at 10^6 cells x 200k loci for 1.6e7 entries, f64-latency bound);
+//   locus side  the minority cells' tier-2 entries are COUNTED per (locus, pair) (k_t2_minority walks the excluded cells'
+//               overflow rows: integer atomics, exact and order independent) and k_locus_finalize turns counts x table values
+//               into the locus' contributions, like it does for the regular entries.  No per-entry values are stored or read.
+// The table row of a locus is six 64-byte sectors [E(n), up to seven log-pmfs of total n]: n = 5, 6, 7 (ref 0..6), 7 (ref 7),
+// 8 (ref 0..6), 8 (ref 7, 8) — an entry's log-pmf and expected term share a sector.
+// What is left for the per-entry paths: totals 0 (quirk Q14) and above 8 (the tier lists on the cell side, `ovx` on the locus side).
+// ---------------------------------------------------------------------------------------------------------
+// The pairs that occur in the shard and the sectors that hold at least one of them are STATIC: two lists made at ingest
+// (k_t2_lists, in locus order).  One thread per listed pair (blocks [0, gp)) or sector (blocks [gp, ...)): dense waves
+// whose lanes all run the same loops.  (A thread per table slot — 48 per locus, most of them idle while a few lanes ran
+// the long expected-term loop — took 0.41 ms beside the tile kernel at 200k loci, 0.30 ms on a 125k-cell shard.)
+// Slots of pairs that do not occur are never written and never read.  A masked locus (alpha < 0) gets zeros: its
+// entries add nothing.
+template <bool EXPECTED>
+__global__ __launch_bounds__(256) void k_t2_tables(uint32_t n_pairs, const uint32_t *__restrict__ plist /*locus << 5 | pair*/,
+                                                   uint32_t n_sec, const uint32_t *__restrict__ slist /*locus << 3 | sector*/,
+                                                   uint32_t gp, const double2 *__restrict__ ab, const double *__restrict__ lf,
+                                                   double *__restrict__ tab2)
+{
+    if (blockIdx.x < gp) {
+        const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+        if (i >= n_pairs) return;
+        const uint32_t key = plist[i], l = key >> 5, c2 = key & 31u;
+        const uint32_t n = 5u + (c2 >= 6u) + (c2 >= 13u) + (c2 >= 21u), r = c2 - t2_code(n, 0u), a = n - r;
+        const double2 p = ab[l];
+        double v = 0.0;
+        if (p.x >= 0.0) {  // = dm_log_bb_pmf for a total of at most DM_CHUNK: one log of a ratio of two short products
+            double num = 1.0, den = 1.0, fa = p.x, fb = p.y, fab = p.x + p.y;
+#pragma unroll
+            for (uint32_t k = 0; k < T2_NMAX; ++k) {  // (one instruction path for every total and split)
+                const bool on = k < n, isa = k < a;
+                num *= on ? (isa ? fa : fb) : 1.0;
+                den *= on ? fab : 1.0;
+                fa += isa ? 1.0 : 0.0;
+                fb += (on && !isa) ? 1.0 : 0.0;
+                fab += 1.0;
+            }
+            v = (lf[n] - lf[a] - lf[r]) + log(num / den);
+        }
+        tab2[(uint64_t)l * T2_ROW + t2_pos(n, r)] = v;
+    } else if (EXPECTED) {
+        const uint32_t i = (blockIdx.x - gp) * 256 + threadIdx.x;
+        if (i >= n_sec) return;
+        const uint32_t key = slist[i], l = key >> 3, sec = key & 7u;
+        const uint32_t n = 5u + (sec >= 1u) + (sec >= 2u) + (sec >= 4u);
+        const double2 p = ab[l];
+        tab2[(uint64_t)l * T2_ROW + sec * 8u] = p.x >= 0.0 ? ov_expected_rec(p.x, p.y, n) : 0.0;
+    }
+}
+
+// the two lists, from the static pair histogram: a thread per locus.  COUNT: pairs / sectors of the locus; FILL: at the offsets
+template <bool FILL>
+__global__ __launch_bounds__(256) void k_t2_lists(uint64_t L, const uint32_t *__restrict__ hist_all2, uint64_t *__restrict__ np,
+                                                  uint64_t *__restrict__ ns, uint32_t *__restrict__ plist, uint32_t *__restrict__ slist,
+                                                  uint32_t *__restrict__ pmask /*FILL: bit c2 = the pair occurs at the locus*/)
+{
+    const uint64_t l = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (l >= L) return;
+    uint64_t kp = FILL ? np[l] : 0, ks = FILL ? ns[l] : 0;
+    uint32_t secs = 0, pm = 0;
+    for (uint32_t c2 = 0; c2 < (uint32_t)T2_NCODE; c2++) {
+        if (hist_all2[l * T2_CSTRIDE + c2] == 0u) continue;
+        const uint32_t n = 5u + (c2 >= 6u) + (c2 >= 13u) + (c2 >= 21u), r = c2 - t2_code(n, 0u);
+        secs |= 1u << (t2_pos(n, r) >> 3);
+        pm |= 1u << c2;
+        if (FILL) plist[kp] = (uint32_t)(l << 5) | c2;
+        kp++;
+    }
+    for (uint32_t sec = 0; sec < 6u; sec++) {
+        if (!((secs >> sec) & 1u)) continue;
+        if (FILL) slist[ks] = (uint32_t)(l << 3) | sec;
+        ks++;
+    }
+    if (!FILL) { np[l] = kp; ns[l] = ks; }
+    else pmask[l] = pm;
+}
+
+// static: how often every tier-2 pair occurs at every locus (all cells of the shard); a thread per overflow entry (by-locus order)
+__global__ __launch_bounds__(256) void k_t2_hist(uint64_t n_ovf, const uint32_t *__restrict__ ovc_locus, const uint64_t *__restrict__ ovc_ent,
+                                                 uint32_t *__restrict__ hist_all2)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_ovf) return;
+    const uint64_t en = ovc_ent[i];
+    const uint32_t r = ENT_REF(en), n = ENT_ALT(en) + r;
+    if (t2_total(n)) atomicAdd(&hist_all2[(uint64_t)ovc_locus[i] * T2_CSTRIDE + t2_code(n, r)], 1u);
+}
+
+// cell side: a thread per cell row of the 64-row ELLPACK copy (coalesced entry loads), four entries' lookups in flight;
+// sums in the row's order (ascending locus): deterministic.  Entries of other totals (0, above 8) are skipped.
+template <bool EXPECTED>
+__global__ __launch_bounds__(256) void k_t2_cell(uint64_t n_rows, const uint64_t *__restrict__ ell_ptr, const uint64_t *__restrict__ ell,
+                                                 const double *__restrict__ tab2, double *__restrict__ o_ll, double *__restrict__ o_ell)
+{
+    const uint64_t row = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= n_rows) return;
+    double s = 0.0, e = 0.0;
+    const uint64_t grp = row >> 6, base = ell_ptr[grp] + (row & 63), end = ell_ptr[grp + 1];
+    constexpr int U = 4;
+    for (uint64_t i = base; i < end; i += (uint64_t)U * 64) {
+        uint64_t en[U];
+        double lp[U], ev[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) en[u] = i + (uint64_t)u * 64 < end ? ell[i + (uint64_t)u * 64] : OVF_PAD;  // (wave-uniform bound)
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const uint32_t r = ENT_REF(en[u]), n = ENT_ALT(en[u]) + r;
+            const bool ok = en[u] != OVF_PAD && t2_total(n);
+            const uint64_t at = (uint64_t)ENT_IDX(en[u]) * T2_ROW + t2_pos(ok ? n : T2_NMIN, ok ? r : 0u);
+            lp[u] = ok ? tab2[at] : 0.0;
+            if (EXPECTED) ev[u] = ok ? tab2[at & ~7ull] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            s += lp[u];
+            if (EXPECTED) e += ev[u];
+        }
+    }
+    o_ll[row] = s;
+    if (EXPECTED) o_ell[row] = e;
+}
+
+// locus side: the tier-2 entries of the cells of the new exclusion set, counted per (locus, pair).  16 lanes per excluded
+// cell walk its overflow row (~16 entries: one 128-byte line); ~10^6 scattered integer atomics per iteration at 10^6 cells.
+// k_locus_finalize reads the counters and clears them again.
+__global__ __launch_bounds__(256) void k_t2_minority(const uint32_t *__restrict__ n_min_p, const uint32_t *__restrict__ minlist,
+                                                     const uint64_t *__restrict__ ovf_ptr, const uint64_t *__restrict__ ovf_ent,
+                                                     uint32_t *__restrict__ cnt2)
+{
+    const uint32_t n_min = *n_min_p;
+    const uint32_t j = threadIdx.x % LF_LANES;
+    const uint32_t ng = gridDim.x * (256 / LF_LANES);
+    for (uint32_t k = (blockIdx.x * 256 + threadIdx.x) / LF_LANES; k < n_min; k += ng) {
+        const uint32_t cell = minlist[k];
+        for (uint64_t i = ovf_ptr[cell] + j, end = ovf_ptr[cell + 1]; i < end; i += LF_LANES) {
+            const uint64_t en = ovf_ent[i];
+            const uint32_t r = ENT_REF(en), n = ENT_ALT(en) + r;
+            if (t2_total(n)) atomicAdd(&cnt2[(uint64_t)ENT_IDX(en) * T2_CSTRIDE + t2_code(n, r)], 1u);
+        }
+    }
+}
+
+// the log-pmfs of the overflow entries OUTSIDE tier 2 (totals 0 and above 8: 1 % of the overflow entries) in by-locus order for
+// the locus finalize: a thread per entry, the tier lists' arithmetic (the cell side adds the same bits)
+__global__ __launch_bounds__(256) void k_ovx_values(uint64_t n_ovx, const uint32_t *__restrict__ ovx_locus, const uint64_t *__restrict__ ovx_ent,
+                                                    const double2 *__restrict__ ab, const double *__restrict__ lf, double *__restrict__ lp_out)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_ovx) return;
+    const uint64_t en = ovx_ent[i];
+    const double2 p = ab[ovx_locus[i]];
+    const uint32_t a = ENT_ALT(en), r = ENT_REF(en), n = a + r;
+    double lp = 0.0;  // a masked locus has no PMFData (main.rs:556); a 0/0 entry is exactly zero (quirk Q14)
+    if (p.x >= 0.0 && n != 0u)
+        lp = n <= (uint32_t)OV_NE ? (lf[n] - lf[a] - lf[r]) + dm_log_beta_ratio(p.x, p.y, a, r) : ov_slow_log_pmf(lf, p.x, p.y, a, r);
+    lp_out[i] = lp;
 }
 
 // 64-row ELLPACK copy of the overflow CSR.  COUNT: slots of group g = 64 x its longest row; FILL: lane = row & 63 writes
@@ -1240,7 +1427,10 @@ __global__ __launch_bounds__(256) void k_locus_finalize(uint64_t L, int locus_mo
                                                         const uint64_t *__restrict__ ovc_ent,
                                                         const double *__restrict__ ovf_lp /*null: evaluate here*/,
                                                         const double *__restrict__ otab, const double *__restrict__ lf,
-                                                        const double2 *__restrict__ ab, double *__restrict__ out)
+                                                        const double2 *__restrict__ ab, double *__restrict__ out,
+                                                        uint32_t *__restrict__ cnt2 /*null: no tier 2*/,
+                                                        const uint32_t *__restrict__ hist_all2, const uint32_t *__restrict__ pmask2,
+                                                        const double *__restrict__ tab2)
 {
     // the minority-driven form left n_sub planes of u16 counts, the streamed form one plane of u32 counts
     const bool by_min = locus_by_minority(locus_mode, *n_min_p, nloc, n_sub);
@@ -1271,6 +1461,28 @@ __global__ __launch_bounds__(256) void k_locus_finalize(uint64_t L, int locus_mo
             nmin = cnt;
             cmin = (double)cnt * t_code;
             cmaj = (double)(h_all - cnt) * t_code;
+        }
+    }
+    // tier 2 (the overflow entries with totals 5..8, counted per (locus, pair) by k_t2_minority): lane j takes the pairs j and
+    // j + 16; count x table value, like the regular codes.  The counters are cleared for the next iteration.
+    if (cnt2) {
+        const uint32_t pm = pmask2[l];  // (the pairs that occur at this locus, static: 8 of the 30 on a 125k-cell shard)
+#pragma unroll
+        for (uint32_t h = 0; h < 2; h++) {
+            const uint32_t c2 = j + h * LF_LANES;
+            if (!((pm >> c2) & 1u)) continue;  // the pair does not occur at this locus: no counts, no table slot
+            const uint32_t h_all = hist_all2[l * T2_CSTRIDE + c2];
+            const uint32_t cnt = cnt2[l * T2_CSTRIDE + c2];
+            if (cnt && in) cnt2[l * T2_CSTRIDE + c2] = 0u;  // (the clamped lanes beyond L only read)
+            const uint32_t n2 = 5u + (c2 >= 6u) + (c2 >= 13u) + (c2 >= 21u), r2 = c2 - t2_code(n2, 0u);
+            const double t_code = tab2[l * T2_ROW + t2_pos(n2, r2)];
+            amin += (uint64_t)cnt * (n2 - r2);
+            rmin += (uint64_t)cnt * r2;
+            if (live) {
+                nmin += cnt;
+                cmin += (double)cnt * t_code;
+                cmaj += (double)(h_all - cnt) * t_code;
+            }
         }
     }
     // overflow entries: four independent entry loads per lane in flight, then their exclusion-bitmask words and their
@@ -1520,8 +1732,9 @@ __global__ __launch_bounds__(T_BC) void k_tile_build(uint64_t nloc, uint32_t nj,
     for (; k < K; k++) dst[1 + k] = T_NULL;
 }
 
-// wave per row/column: count entries that are NOT regular (FILL = false) or copy them in order (FILL = true)
-template <bool FILL>
+// wave per row/column: count entries that are NOT regular (FILL = false) or copy them in order (FILL = true);
+// REST: only those outside tier 2 as well (totals 0 and above 8)
+template <bool FILL, bool REST = false>
 __global__ __launch_bounds__(256) void k_ovf_build(uint64_t n_rows, const uint64_t *__restrict__ ptr,
                                                    const uint64_t *__restrict__ ent, uint64_t *__restrict__ optr,
                                                    uint64_t *__restrict__ oent)
@@ -1534,7 +1747,7 @@ __global__ __launch_bounds__(256) void k_ovf_build(uint64_t n_rows, const uint64
         for (uint64_t i0 = beg; i0 < end; i0 += 64) {
             const uint64_t i = i0 + lane;
             const uint64_t e = i < end ? ent[i] : 0;
-            const bool ov = i < end && !ent_regular(e);
+            const bool ov = i < end && !ent_regular(e) && !(REST && t2_total(ENT_ALT(e) + ENT_REF(e)));
             const unsigned long long m = __ballot(ov);
             if (FILL && ov) oent[base + __popcll(m & ((1ull << lane) - 1ull))] = e;
             base += __popcll(m);
@@ -1599,6 +1812,8 @@ void tiled_free(cellector_ctx *c)
     dev_free(c->hist_all); dev_free(c->tab); dev_free(c->part); dev_free(c->ab3);
     dev_free(c->masked_cnt); dev_free(c->flag_bits); dev_free(c->ovf_tab); dev_free(c->ovf_etab);
     dev_free(c->ovf_sum); dev_free(c->ovf_lp); dev_free(c->ovc_locus); dev_free(c->ovf_tier_row[0]); dev_free(c->ovf_tier_row[1]); dev_free(c->ovf_tier_ent[0]); dev_free(c->ovf_tier_ent[1]); dev_free(c->ovf_tier_val); dev_free(c->ovf_ell_ptr); dev_free(c->ovf_ell); dev_free(c->ovf_nmask); dev_free(c->tile_work); dev_free(c->minlist); dev_free(c->hist_min); dev_free(c->roff); dev_free(c->c4r); dev_free(c->mroff); dev_free(c->mbeg);
+    dev_free(c->t2_plist); dev_free(c->t2_slist); dev_free(c->t2_pmask); dev_free(c->hist_all2); dev_free(c->cnt2); dev_free(c->tab2); dev_free(c->ovx_ptr); dev_free(c->ovx_ent); dev_free(c->ovx_locus); dev_free(c->ovx_lp);
+    c->ovx_n = 0; c->t2 = false;
     c->mroff_cap = 0;
     c->tiled_ready = false;
     c->ovf_n = 0; c->n_masked_loci = 0;
@@ -1731,14 +1946,70 @@ cellector_status tiled_build(cellector_ctx *c)
     }
     HIPCHK(c, hipGetLastError());
 
-    // ---- overflow values: by-locus storage + permutation for the by-cell gather
+    // ---- overflow entries: which paths they take
     if (c->ovf_n >= (1ull << 32)) return ctx_fail(c, CELLECTOR_EINVAL, "tiled engine: more than 2^32 overflow entries per shard");
+    // deep coverage: more than 3 % of the entries outside the tables (0.8 % with vartrix-like totals 1 + Geometric(0.7),
+    // 13 % with 1 + Geometric(0.4)) — the side-stream arrangement built for "a few entries per row" no longer hides them
+    c->ovf_deep = c->ovf_deep_opt >= 0 ? c->ovf_deep_opt != 0 : (c->ovf_n * 100 > c->nnz * 3);
+    c->t2 = c->ovf_n != 0 && L != 0 && L < (1ull << 27) /* the pair list's keys */ && (c->t2_opt >= 0 ? c->t2_opt != 0 : !c->ovf_deep);
     CHK(dev_alloc(c, &c->ovf_sum, 3 * 2 * nloc));
     CHK(dev_alloc(c, &c->ovf_tab, L * OV_ROW));
-    CHK(dev_alloc(c, &c->ovf_lp, c->ovf_n));
     CHK(dev_alloc(c, &c->ovc_locus, c->ovf_n));
-    CHK(dev_alloc(c, &c->ovf_etab, L * OV_REC));
+    if (L && c->ovf_n)
+        hipLaunchKernelGGL(k_ovf_locus_ids, dim3(gcap(L, 4)), dim3(256), 0, c->stream, L, c->ovc_ptr, c->ovc_locus);
+    if (!(c->t2 && !c->ovf_deep)) {  // (the per-entry paths of a shard without tier 2, and the deep forms)
+        CHK(dev_alloc(c, &c->ovf_lp, c->ovf_n));
+        CHK(dev_alloc(c, &c->ovf_etab, L * OV_REC));
+    }
     CHK(dev_alloc(c, &c->ovf_nmask, L));
+    c->ovx_n = 0;
+    if (c->t2) {
+        // tier 2: static pair histogram, per-iteration counters and table; the by-locus CSC of the entries outside it
+        CHK(dev_alloc(c, &c->hist_all2, L * T2_CSTRIDE));
+        CHK(dev_alloc(c, &c->cnt2, L * T2_CSTRIDE));
+        CHK(dev_alloc(c, &c->tab2, L * T2_ROW));
+        HIPCHK(c, hipMemsetAsync(c->hist_all2, 0, L * T2_CSTRIDE * sizeof(uint32_t), c->stream));
+        HIPCHK(c, hipMemsetAsync(c->cnt2, 0, L * T2_CSTRIDE * sizeof(uint32_t), c->stream));
+        hipLaunchKernelGGL(k_t2_hist, dim3(gcap(c->ovf_n, 256, 0x7fffffffu)), dim3(256), 0, c->stream, c->ovf_n, c->ovc_locus, c->ovc_ent,
+                           c->hist_all2);
+        {
+            uint64_t *np = nullptr, *ns = nullptr, tot_p = 0, tot_s = 0;
+            CHK(dev_alloc(c, &np, L + 1));
+            CHK(dev_alloc(c, &ns, L + 1));
+            HIPCHK(c, hipMemsetAsync(np + L, 0, 8, c->stream));
+            HIPCHK(c, hipMemsetAsync(ns + L, 0, 8, c->stream));
+            hipLaunchKernelGGL(k_t2_lists<false>, dim3(gcap(L, 256)), dim3(256), 0, c->stream, L, c->hist_all2, np, ns, (uint32_t *)nullptr,
+                               (uint32_t *)nullptr, (uint32_t *)nullptr);
+            cellector_status st = dev_exclusive_scan_u64(c, np, L + 1, &tot_p);
+            if (st == CELLECTOR_OK) st = dev_exclusive_scan_u64(c, ns, L + 1, &tot_s);
+            if (st == CELLECTOR_OK) st = dev_alloc(c, &c->t2_plist, tot_p);
+            if (st == CELLECTOR_OK) st = dev_alloc(c, &c->t2_slist, tot_s);
+            if (st == CELLECTOR_OK) st = dev_alloc(c, &c->t2_pmask, L);
+            if (st == CELLECTOR_OK) {
+                hipLaunchKernelGGL(k_t2_lists<true>, dim3(gcap(L, 256)), dim3(256), 0, c->stream, L, c->hist_all2, np, ns, c->t2_plist, c->t2_slist,
+                                   c->t2_pmask);
+                if (hipStreamSynchronize(c->stream) != hipSuccess) st = ctx_fail(c, CELLECTOR_EDEVICE, "tier-2 list build failed");
+            }
+            dev_free(np); dev_free(ns);
+            CHK(st);
+            c->t2_np = (uint32_t)tot_p; c->t2_ns = (uint32_t)tot_s;
+        }
+        CHK(dev_alloc(c, &c->ovx_ptr, L + 1));
+        HIPCHK(c, hipMemsetAsync(c->ovx_ptr + L, 0, 8, c->stream));
+        hipLaunchKernelGGL((k_ovf_build<false, true>), dim3(gcap(L, 4)), dim3(256), 0, c->stream, L, c->ovc_ptr, c->ovc_ent, c->ovx_ptr,
+                           (uint64_t *)nullptr);
+        CHK(dev_exclusive_scan_u64(c, c->ovx_ptr, L + 1, &c->ovx_n));
+        CHK(dev_alloc(c, &c->ovx_ent, c->ovx_n));
+        CHK(dev_alloc(c, &c->ovx_locus, c->ovx_n));
+        CHK(dev_alloc(c, &c->ovx_lp, c->ovx_n));
+        hipLaunchKernelGGL((k_ovf_build<true, true>), dim3(gcap(L, 4)), dim3(256), 0, c->stream, L, c->ovc_ptr, c->ovc_ent, c->ovx_ptr,
+                           c->ovx_ent);
+        if (c->ovx_n)
+            hipLaunchKernelGGL(k_ovf_locus_ids, dim3(gcap(L, 4)), dim3(256), 0, c->stream, L, c->ovx_ptr, c->ovx_locus);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        dev_free(c->ovc_locus);  // (only the histogram needed it)
+    }
     {
         const uint64_t n_grp = (nloc + 63) / 64;
         uint64_t slots = 0;
@@ -1780,10 +2051,14 @@ cellector_status tiled_build(cellector_ctx *c)
         CHK(st);
         CHK(dev_alloc(c, &c->ovf_tier_val, 2 * c->ovf_n_tier[1]));  // (log-pmf, expected term) of the tier-1 entries, per pass
     }
-    if (L && c->ovf_n)
-        hipLaunchKernelGGL(k_ovf_locus_ids, dim3(gcap(L, 4)), dim3(256), 0, c->stream, L, c->ovc_ptr, c->ovc_locus);
-    if (L && c->ovf_n)
-        hipLaunchKernelGGL(k_ovf_nmask, dim3(gcap(L, 4)), dim3(256), 0, c->stream, L, c->ovc_ptr, c->ovc_ent, c->ovf_nmask);
+    // which totals the per-entry tables (k_ovf_tables, k_ovf_tables_e) must cover at every locus: those of the entries that
+    // take these paths
+    if (L && c->ovf_n) {
+        if (c->t2)
+            hipLaunchKernelGGL(k_ovf_nmask, dim3(gcap(L, 4)), dim3(256), 0, c->stream, L, c->ovx_ptr, c->ovx_ent, c->ovf_nmask);
+        else
+            hipLaunchKernelGGL(k_ovf_nmask, dim3(gcap(L, 4)), dim3(256), 0, c->stream, L, c->ovc_ptr, c->ovc_ent, c->ovf_nmask);
+    }
     HIPCHK(c, hipGetLastError());
 
     // ---- per-iteration workspaces
@@ -1822,9 +2097,6 @@ cellector_status tiled_build(cellector_ctx *c)
     HIPCHK(c, hipMemsetAsync(c->masked_cnt, 0, (nloc ? nloc : 1) * 4, c->stream));
     HIPCHK(c, hipMemsetAsync(c->flag_bits, 0, ((nloc + 31) / 32 + 1) * 4, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    // deep coverage: more than 3 % of the entries outside the tables (0.8 % with vartrix-like totals 1 + Geometric(0.7),
-    // 13 % with 1 + Geometric(0.4)) — the side-stream arrangement built for "a few entries per row" no longer hides them
-    c->ovf_deep = c->ovf_deep_opt >= 0 ? c->ovf_deep_opt != 0 : (c->ovf_n * 100 > c->nnz * 3);
     c->tiled_ready = true;
     return CELLECTOR_OK;
 }
@@ -1837,6 +2109,38 @@ static void launch_overflow_cell(cellector_ctx *c, hipStream_t st, const double2
     double *o_ll = c->ovf_sum + (uint64_t)set * 2 * c->nloc, *o_ell = o_ll + c->nloc;
     const unsigned g = gcap(c->nloc, 256, 0x7fffffffu), eg = gcap(c->L * 16, 256, 0x7fffffffu);
     const bool deep = c->ovf_deep;  // the overflow share is large: full form, never throttled, no tier-0 list
+    if (c->t2) {
+        // tier 2: the pairs' table of this pass, then the rows' lookups (writes the sums); the other totals ADD to them
+        const unsigned gp = gcap(c->t2_np, 256, 0x7fffffffu), gs = expected ? gcap(c->t2_ns, 256, 0x7fffffffu) : 0u;
+        // Residency throttle: a request for dynamic LDS it does not use leaves room for only ONE block of the lookup kernel beside
+        // a tile workgroup (one wave per SIMD).  On a big shard its gathers then disturb the tile kernel less (10^6 cells x 200k
+        // loci: 2.38 -> 2.31 ms per iteration); a small shard's tile kernel is too short for that.
+        const size_t lds_req = deep ? 0 : c->side_lds >= 0 ? (size_t)c->side_lds : (st == c->side && c->nloc >= (1ull << 19) ? 5000 : 0);
+        const bool need_e = expected && (deep || c->ovf_n_tier[0]);  // E(9..17) of the tier-0 entries
+#define T2_CELL(E)                                                                                                         \
+        do {                                                                                                               \
+            hipLaunchKernelGGL(k_t2_tables<E>, dim3(gp + gs), dim3(256), 0, st, c->t2_np, c->t2_plist, c->t2_ns, c->t2_slist, gp, ab, c->lf, \
+                               c->tab2);                                                                                   \
+            hipLaunchKernelGGL(k_t2_cell<E>, dim3(g), dim3(256), lds_req, st, c->nloc, c->ovf_ell_ptr, c->ovf_ell, c->tab2, o_ll, o_ell); \
+            if (need_e)                                                                                                    \
+                hipLaunchKernelGGL(k_ovf_tables_e, dim3(eg), dim3(256), 0, st, c->L, ab, c->ovf_nmask, c->ovf_tab, c->ovf_etab); \
+            if (deep)                                                                                                      \
+                hipLaunchKernelGGL((k_ovf_cell_wide<E, true>), dim3(gcap(c->nloc * LF_LANES, 256, 0x7fffffffu)), dim3(256), 0, st, c->nloc, \
+                                   c->ovf_ptr, c->ovf_ent, ab, c->lf, c->ovf_etab, c->ovf_tab, o_ll, o_ell);               \
+            else if (c->ovf_n_tier[0])                                                                                     \
+                hipLaunchKernelGGL((k_ovf_cell_listed<E, false>), dim3(gcap(c->ovf_n_tier[0], 256, 0x7fffffffu)), dim3(256), 0, st, \
+                                   c->ovf_n_tier[0], c->ovf_tier_row[0], c->ovf_tier_ent[0], ab, c->lf, c->ovf_tab, o_ll, o_ell); \
+            if (c->ovf_n_tier[1]) {                                                                                        \
+                hipLaunchKernelGGL(k_ovf_listed_values<E>, dim3(gcap(c->ovf_n_tier[1] * LF_LANES, 256, 0x7fffffffu)), dim3(256), 0, st, \
+                                   c->ovf_n_tier[1], c->ovf_tier_ent[1], ab, c->lf, c->ovf_tier_val, c->ovf_tier_val + c->ovf_n_tier[1]); \
+                hipLaunchKernelGGL(k_ovf_listed_add<E>, dim3(gcap(c->ovf_n_tier[1], 256, 0x7fffffffu)), dim3(256), 0, st, c->ovf_n_tier[1], \
+                                   c->ovf_tier_row[1], c->ovf_tier_val, c->ovf_tier_val + c->ovf_n_tier[1], o_ll, o_ell);  \
+            }                                                                                                              \
+        } while (0)
+        if (expected) T2_CELL(true); else T2_CELL(false);
+#undef T2_CELL
+        return;
+    }
     if (expected) {
         hipLaunchKernelGGL(k_ovf_tables_e, dim3(eg), dim3(256), 0, st, c->L, ab, c->ovf_nmask, c->ovf_tab, c->ovf_etab);
         // Residency throttle: a request for dynamic LDS it does not use leaves room for only ONE block of this kernel beside
@@ -1844,7 +2148,7 @@ static void launch_overflow_cell(cellector_ctx *c, hipStream_t st, const double2
         // kernel and disturbs it less (cfg4: 2.83 -> 2.78 ms per iteration); a small shard's tile kernel is too short for that.
         const size_t lds_req = deep ? 0 : c->side_lds >= 0 ? (size_t)c->side_lds : (st == c->side && c->nloc >= (1ull << 19) ? 5000 : 0);
         if (deep && c->ovf_deep_wide)
-            hipLaunchKernelGGL(k_ovf_cell_wide<true>, dim3(gcap(c->nloc * LF_LANES, 256, 0x7fffffffu)), dim3(256), 0, st, c->nloc, c->ovf_ptr,
+            hipLaunchKernelGGL((k_ovf_cell_wide<true, false>), dim3(gcap(c->nloc * LF_LANES, 256, 0x7fffffffu)), dim3(256), 0, st, c->nloc, c->ovf_ptr,
                                c->ovf_ent, ab, c->lf, c->ovf_etab, c->ovf_tab, o_ll, o_ell);
         else if (deep)
             hipLaunchKernelGGL((k_ovf_cell_direct<true, false, true>), dim3(g), dim3(256), 0, st, c->nloc, c->ovf_ell_ptr, c->ovf_ell, ab,
@@ -1866,7 +2170,7 @@ static void launch_overflow_cell(cellector_ctx *c, hipStream_t st, const double2
         }
     } else {
         if (deep && c->ovf_deep_wide)
-            hipLaunchKernelGGL(k_ovf_cell_wide<false>, dim3(gcap(c->nloc * LF_LANES, 256, 0x7fffffffu)), dim3(256), 0, st, c->nloc, c->ovf_ptr,
+            hipLaunchKernelGGL((k_ovf_cell_wide<false, false>), dim3(gcap(c->nloc * LF_LANES, 256, 0x7fffffffu)), dim3(256), 0, st, c->nloc, c->ovf_ptr,
                                c->ovf_ent, ab, c->lf, c->ovf_etab, c->ovf_tab, o_ll, o_ell);
         else if (deep)
             hipLaunchKernelGGL((k_ovf_cell_direct<false, false, true>), dim3(g), dim3(256), 0, st, c->nloc, c->ovf_ell_ptr, c->ovf_ell, ab, c->lf,
@@ -1888,6 +2192,12 @@ static void launch_overflow_cell(cellector_ctx *c, hipStream_t st, const double2
 // locus side: the per-locus cumulative-log tables that k_locus_finalize evaluates the overflow entries' log-pmfs from, on stream `st`
 static void launch_overflow_locus_values(cellector_ctx *c, hipStream_t st, const double2 *ab)
 {
+    if (c->t2 && !c->ovf_deep) {  // tier 2 needs nothing here (k_t2_tables is the cell side's first kernel); the few other entries:
+        if (c->ovx_n)
+            hipLaunchKernelGGL(k_ovx_values, dim3(gcap(c->ovx_n, 256, 0x7fffffffu)), dim3(256), 0, st, c->ovx_n, c->ovx_locus, c->ovx_ent, ab,
+                               c->lf, c->ovx_lp);
+        return;
+    }
     hipLaunchKernelGGL(k_ovf_tables, dim3(gcap(c->L * 3, 256, 0x7fffffffu)), dim3(256), 0, st, c->L, ab, c->ovf_nmask, c->ovf_tab);
     if (!c->ovf_deep)  // shallow coverage: the values are stored here, beside the tile kernel, and the finalize reads them
         hipLaunchKernelGGL(k_ovf_values, dim3(gcap(c->ovf_n, 256, 0x7fffffffu)), dim3(256), 0, st, c->ovf_n, c->ovc_locus, c->ovc_ent, ab,
@@ -2089,15 +2399,22 @@ cellector_status tiled_locus_pass(cellector_ctx *c)
         hipLaunchKernelGGL(k_minority_ranges, dim3(R * c->lr_sub), dim3(LR_THREADS), 0, c->stream, c->locus_mode, c->nloc, c->L, R,
                            c->lr_sub, c->mroff_cap, c->d_counters + DC_N_MIN, c->mroff, c->mbeg, c->c4r, c->hist_min);
     }
+    if (c->t2 && c->nloc)  // the excluded cells' tier-2 entries per (locus, pair)
+        hipLaunchKernelGGL(k_t2_minority, dim3(gcap(c->nloc, 256 / LF_LANES, 1024)), dim3(256), 0, c->stream, c->d_counters + DC_N_MIN,
+                           c->minlist, c->ovf_ptr, c->ovf_ent, c->cnt2);
     if (c->ovf_locus_pending) {  // the overflow entries' log-pmfs of this iteration (side stream)
         HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join2, 0));
         c->ovf_locus_pending = false;
     }
+    // the entries the finalize walks one by one: all overflow entries, or (tier 2) those outside tier 2
+    const uint64_t *w_ptr = c->t2 ? (c->ovx_n ? c->ovx_ptr : nullptr) : (c->ovf_n ? c->ovc_ptr : nullptr);
+    const uint64_t *w_ent = c->t2 ? c->ovx_ent : c->ovc_ent;
+    const double *w_lp = c->t2 ? c->ovx_lp : c->ovf_lp;
 #define LAUNCH_LF(INL)                                                                                                             \
     hipLaunchKernelGGL(k_locus_finalize<INL>, dim3(gcap(c->L * LF_LANES, 256, 0x7fffffffu)), dim3(256), 0, c->stream, c->L, c->locus_mode, \
                        c->nloc, c->lr_sub, c->d_counters + DC_N_MIN, c->hist_min, c->flag_bits, c->hist_all, c->tab_em,            \
-                       (uint32_t)c->tab_em_stride, c->mask, c->ovf_n ? c->ovc_ptr : (const uint64_t *)nullptr, c->ovc_ent, c->ovf_lp, \
-                       c->ovf_tab, c->lf, c->ab, c->x_locus)
+                       (uint32_t)c->tab_em_stride, c->mask, w_ptr, w_ent, w_lp, c->ovf_tab, c->lf, c->ab, c->x_locus,              \
+                       c->t2 ? c->cnt2 : (uint32_t *)nullptr, c->hist_all2, c->t2_pmask, c->tab2)
     if (c->ovf_deep) LAUNCH_LF(true); else LAUNCH_LF(false);
 #undef LAUNCH_LF
     timer_end(c, CELLECTOR_K_LOCUS_STATS);

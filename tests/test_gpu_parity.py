@@ -222,12 +222,17 @@ def test_overflow_side_stream_equals_in_stream(mods):
     # ... and, last, the form a matrix with this many such entries gets by itself (ovf_deep: one unthrottled kernel for
     # totals up to 17): same values within rounding — the summation order inside a row's overflow entries differs
     # (the deep form has two kernels: 16 lanes per row — the default — and a thread per row)
-    for ov, lds, deep, wide in ((1, -1, 0, 1), (0, -1, 0, 1), (2, -1, 0, 1), (1, 5000, 0, 1), (1, -1, -1, 1), (0, -1, 1, 1), (1, -1, 1, 0)):
+    # (t2: the entries with totals 5..8 through per-(locus, pair) tables — the default unless the matrix is deep — or, 0, one by
+    # one like the other totals: same values within rounding)
+    variants = ((1, -1, 0, 1, -1), (0, -1, 0, 1, -1), (2, -1, 0, 1, -1), (1, 5000, 0, 1, -1), (1, -1, 0, 1, 0), (1, -1, -1, 1, -1),
+                (0, -1, 1, 1, -1), (1, -1, 1, 0, -1), (1, -1, 1, 1, 1), (0, -1, 1, 1, 1))
+    for ov, lds, deep, wide, t2 in variants:
         g = mods["Cellector"](0)
         g.set_option("overlap", ov)
         g.set_option("side_lds", lds)
         g.set_option("ovf_deep", deep)
         g.set_option("ovf_deep_wide", wide)
+        g.set_option("t2", t2)
         g.load_coo(L, N, lo, ce, al, re)
         o = mods["ob"].Oracle.from_coo(L, N, lo, ce, al, re)
         run = []
@@ -252,10 +257,13 @@ def test_overflow_side_stream_equals_in_stream(mods):
                 assert same(la[k], lb[k]), (vi, k)
         for k in post_a:
             assert same(post_a[k], post_b[k]), (vi, k)
-    # the two deep-form runs (beside the lookup kernel / in one stream) agree to the bit
-    for (ca, la), (cb, lb) in zip(outs[4][0], outs[5][0]):
-        for k in ca:
-            assert np.array_equal(ca[k], cb[k]), k
+    # the deep-form runs beside the lookup kernel / in one stream agree to the bit, without and with tier-2 tables
+    for i, j in ((5, 6), (8, 9)):
+        for (ca, la), (cb, lb) in zip(outs[i][0], outs[j][0]):
+            for k in ca:
+                assert np.array_equal(ca[k], cb[k]), (i, j, k)
+            for k in la:
+                assert np.array_equal(la[k], lb[k]), (i, j, k)
 
 
 def test_device_text_writer_round_trip(mods, tmp_path):
