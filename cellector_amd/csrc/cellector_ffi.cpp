@@ -342,6 +342,10 @@ cellector_status cellector_set_option(cellector_ctx *c, const char *key, int64_t
             return ctx_fail(c, CELLECTOR_EINVAL, "ovf_deep decides which overflow layouts the ingest builds: set it before the ingest");
         c->ovf_deep_opt = (int)v;
     }
+    else if (!strcmp(key, "t2_waves")) {
+        if (v < 1 || v > (1 << 20)) return ctx_fail(c, CELLECTOR_EINVAL, "t2_waves must be within 1..2^20");
+        c->t2_waves = (int)v;
+    }
     else if (!strcmp(key, "t2")) {
         if (v < -1 || v > 1) return ctx_fail(c, CELLECTOR_EINVAL, "t2 must be -1 (automatic), 0 or 1");
         if (c->tiled_ready && v >= 0 && c->t2 != (v != 0))

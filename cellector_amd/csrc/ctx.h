@@ -145,6 +145,7 @@ struct cellector_ctx {
     // tier 2 (kernels_tiled.hip, k_t2_tables): the overflow entries with totals 5..8 are table-driven as well
     int t2_opt = -1;                 // option "t2": -1 = decided per matrix (tiled_build: on unless the matrix is ovf_deep), 0 / 1 = forced
     bool t2 = false;
+    int t2_waves = 512;              // option "t2_waves": one-wave blocks of k_t2_cell when it runs beside the tile kernel
     uint32_t *hist_all2 = nullptr;   // [L][32] tier-2 entries per (locus, pair), all cells of the shard (static)
     uint32_t *t2_plist = nullptr, *t2_slist = nullptr;  // the pairs (locus << 5 | pair) / table sectors (locus << 3 | sector) that occur, locus order (static)
     uint32_t t2_np = 0, t2_ns = 0;

@@ -25,6 +25,7 @@
 //               24/32-bit entries (cell | code) past the exclusion bitmask in LDS (k_locus_stats2); chosen on the device.
 //   overflow    entries with n == 0 or n > 4 (~1 %) live in a small CSR/CSC in the v1 packed format; the cell side
 //               evaluates them itself, the locus side from per-locus cumulative-log tables (see below).
+#include <algorithm>
 #include <type_traits>
 
 #include "ctx.h"
@@ -806,14 +807,20 @@ __global__ __launch_bounds__(256) void k_t2_hist(uint64_t n_ovf, const uint32_t 
 
 // cell side: a thread per cell row of the 64-row ELLPACK copy (coalesced entry loads), four entries' lookups in flight;
 // sums in the row's order (ascending locus): deterministic.  Entries of other totals (0, above 8) are skipped.
+// One-wave blocks that stride over the 64-row groups: the launch's grid size sets how many gathers are in flight chip-wide.
+// Beside the tile kernel a SMALL grid is the point — every lookup fetches a line out of a table far bigger than an L2, and
+// 1.6e7 of them in a burst (2 GB at 5 TB/s) starve the tile kernel's stream for the burst's duration (+0.2 ms at 10^6 cells x 200k
+// loci); spread over the tile kernel's run time the same lines cost it far less (launch_overflow_cell).
 template <bool EXPECTED>
-__global__ __launch_bounds__(256) void k_t2_cell(uint64_t n_rows, const uint64_t *__restrict__ ell_ptr, const uint64_t *__restrict__ ell,
-                                                 const double *__restrict__ tab2, double *__restrict__ o_ll, double *__restrict__ o_ell)
+__global__ __launch_bounds__(64) void k_t2_cell(uint64_t n_rows, const uint64_t *__restrict__ ell_ptr, const uint64_t *__restrict__ ell,
+                                                const double *__restrict__ tab2, double *__restrict__ o_ll, double *__restrict__ o_ell)
 {
-    const uint64_t row = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (row >= n_rows) return;
+  const uint64_t n_grp = (n_rows + 63) >> 6;
+  for (uint64_t grp = blockIdx.x; grp < n_grp; grp += gridDim.x) {
+    const uint64_t row = grp * 64 + threadIdx.x;
+    if (row >= n_rows) continue;
     double s = 0.0, e = 0.0;
-    const uint64_t grp = row >> 6, base = ell_ptr[grp] + (row & 63), end = ell_ptr[grp + 1];
+    const uint64_t base = ell_ptr[grp] + (row & 63), end = ell_ptr[grp + 1];
     constexpr int U = 4;
     for (uint64_t i = base; i < end; i += (uint64_t)U * 64) {
         uint64_t en[U];
@@ -836,6 +843,7 @@ __global__ __launch_bounds__(256) void k_t2_cell(uint64_t n_rows, const uint64_t
     }
     o_ll[row] = s;
     if (EXPECTED) o_ell[row] = e;
+  }
 }
 
 // locus side: the tier-2 entries of the cells of the new exclusion set, counted per (locus, pair).  16 lanes per excluded
@@ -2112,16 +2120,17 @@ static void launch_overflow_cell(cellector_ctx *c, hipStream_t st, const double2
     if (c->t2) {
         // tier 2: the pairs' table of this pass, then the rows' lookups (writes the sums); the other totals ADD to them
         const unsigned gp = gcap(c->t2_np, 256, 0x7fffffffu), gs = expected ? gcap(c->t2_ns, 256, 0x7fffffffu) : 0u;
-        // Residency throttle: a request for dynamic LDS it does not use leaves room for only ONE block of the lookup kernel beside
-        // a tile workgroup (one wave per SIMD).  On a big shard its gathers then disturb the tile kernel less (10^6 cells x 200k
-        // loci: 2.38 -> 2.31 ms per iteration); a small shard's tile kernel is too short for that.
-        const size_t lds_req = deep ? 0 : c->side_lds >= 0 ? (size_t)c->side_lds : (st == c->side && c->nloc >= (1ull << 19) ? 5000 : 0);
+        // (side_lds > 0: a request for dynamic LDS the lookup kernel does not use, to limit its blocks per CU in A/B runs)
+        const size_t lds_req = c->side_lds > 0 ? (size_t)c->side_lds : 0;
+        // waves of the lookup kernel: all groups at once when it has the machine to itself, option t2_waves (default 512) beside the tile kernel
+        const uint64_t n_grp = (c->nloc + 63) / 64;
+        const unsigned cg = (unsigned)std::min<uint64_t>(n_grp ? n_grp : 1, st == c->side && !deep ? (uint64_t)c->t2_waves : 0x7fffffffull);
         const bool need_e = expected && (deep || c->ovf_n_tier[0]);  // E(9..17) of the tier-0 entries
 #define T2_CELL(E)                                                                                                         \
         do {                                                                                                               \
             hipLaunchKernelGGL(k_t2_tables<E>, dim3(gp + gs), dim3(256), 0, st, c->t2_np, c->t2_plist, c->t2_ns, c->t2_slist, gp, ab, c->lf, \
                                c->tab2);                                                                                   \
-            hipLaunchKernelGGL(k_t2_cell<E>, dim3(g), dim3(256), lds_req, st, c->nloc, c->ovf_ell_ptr, c->ovf_ell, c->tab2, o_ll, o_ell); \
+            hipLaunchKernelGGL(k_t2_cell<E>, dim3(cg), dim3(64), lds_req, st, c->nloc, c->ovf_ell_ptr, c->ovf_ell, c->tab2, o_ll, o_ell); \
             if (need_e)                                                                                                    \
                 hipLaunchKernelGGL(k_ovf_tables_e, dim3(eg), dim3(256), 0, st, c->L, ab, c->ovf_nmask, c->ovf_tab, c->ovf_etab); \
             if (deep)                                                                                                      \
