@@ -155,18 +155,31 @@ hipError_t dev_cache_malloc(void **p, size_t bytes)
 void dev_cache_free(void *p)
 {
     if (!p) return;
+    DevBlock blk{};
+    bool cached = false;
     {
         std::lock_guard<std::mutex> lk(g_cache_mu);
         auto it = g_cache_live.find(p);
         if (it != g_cache_live.end()) {
-            // hipFree would have waited for the device; a block handed out again must not still be in use either
-            (void)hipDeviceSynchronize();
-            g_cache_free.push_back(it->second);
+            blk = it->second;
             g_cache_live.erase(it);
-            return;
+            cached = true;
         }
     }
-    (void)hipFree(p);
+    if (!cached) {
+        (void)hipFree(p);
+        return;
+    }
+    // hipFree would have waited for the block's device; a block handed out again must not still be in use either.  The wait is
+    // for the BLOCK's device (a shard thread may free another shard's block) and happens outside the lock: other shards'
+    // allocations do not queue behind it.
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    if (cur != blk.device) (void)hipSetDevice(blk.device);
+    (void)hipDeviceSynchronize();
+    if (cur != blk.device) (void)hipSetDevice(cur);
+    std::lock_guard<std::mutex> lk(g_cache_mu);
+    g_cache_free.push_back(blk);
 }
 
 // a block nobody has used yet goes to the free list as it is (no device synchronisation needed)
@@ -176,12 +189,17 @@ void dev_cache_park(void *p, size_t bytes, int device)
     g_cache_free.push_back(DevBlock{p, bytes, device});
 }
 
-void dev_cache_trim()
+void dev_cache_trim(int device)
 {
     std::vector<DevBlock> blocks;
     {
         std::lock_guard<std::mutex> lk(g_cache_mu);
-        blocks.swap(g_cache_free);
+        if (device < 0) blocks.swap(g_cache_free);
+        else {  // only this device's blocks: the other shards of a multi-device ctx may still be building from theirs
+            std::vector<DevBlock> keep;
+            for (const DevBlock &b : g_cache_free) (b.device == device ? blocks : keep).push_back(b);
+            g_cache_free.swap(keep);
+        }
     }
     int cur = 0;
     (void)hipGetDevice(&cur);
@@ -316,6 +334,10 @@ cellector_status cellector_set_option(cellector_ctx *c, const char *key, int64_t
     if (!c || !key) return CELLECTOR_EINVAL;
     if (c->multi) return multi_set_option(c, key, v);
     if (!strcmp(key, "compute_expected")) c->compute_expected = v != 0;
+    else if (!strcmp(key, "ref_arith")) {
+        if (v && c->engine != 1) return ctx_fail(c, CELLECTOR_EINVAL, "ref_arith evaluates every entry with the reference's ln_gamma arithmetic: an engine 1 option (set engine 1 first)");
+        c->ref_arith = v != 0;
+    }
     else if (!strcmp(key, "timing")) {
         c->timing = v < 0 ? 0 : (v > 2 ? 2 : (int)v);
         if (c->timing && hipSetDevice(c->device) == hipSuccess)  // events ready before the timed loop starts
@@ -376,6 +398,7 @@ cellector_status cellector_set_option(cellector_ctx *c, const char *key, int64_t
             if (c->n_masked_loci) return ctx_fail(c, CELLECTOR_EINVAL, "switch to engine 2 before any locus is masked");
             CHK(tiled_build(c));
         }
+        if (v == 2 && c->ref_arith) return ctx_fail(c, CELLECTOR_EINVAL, "ref_arith is an engine 1 option: clear it before switching to engine 2");
         c->engine = (int)v;
     }
     else return ctx_fail(c, CELLECTOR_EINVAL, "unknown option '%s'", key);
@@ -569,6 +592,21 @@ cellector_status cellector_ingest_finish(cellector_ctx *c, uint64_t min_alt, uin
     HIPCHK(c, hipMemsetAsync(c->x_norm, 0, (need_norm ? need_norm : 1) * 8, c->stream));
     HIPCHK(c, hipMemsetAsync(c->x_locus, 0, need_locus * 8, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    {
+        // The near-tie band of cellector_iter_summary.n_near_threshold follows the matrix' depth: the reference's ln_gamma
+        // differences (stats.rs:41-53) carry ~eps * lnGamma(alpha + beta) of cancellation error per term, which the device's
+        // product form does not reproduce — 1e-11 on a normalised LL at alpha + beta ~ 1e4 (vartrix-like depth), 1e-8 at 1e6.
+        // band = max(1e-9, 8 eps lnGamma(max over the used loci of S_alt + S_ref + 2)), relative to max(1, |threshold|);
+        // the global totals are the same on every shard.
+        std::vector<double> sa(L), sr(L);
+        if (L) {
+            HIPCHK(c, hipMemcpy(sa.data(), c->s_alt, L * 8, hipMemcpyDeviceToHost));
+            HIPCHK(c, hipMemcpy(sr.data(), c->s_ref, L * 8, hipMemcpyDeviceToHost));
+        }
+        double max_ab = 2.0;
+        for (uint64_t l = 0; l < L; l++) max_ab = std::max(max_ab, sa[l] + sr[l] + 2.0);
+        c->near_rel = std::max(CELLECTOR_NEAR_TIE_REL, 8.0 * 2.220446049250313e-16 * lgamma(max_ab));
+    }
     if (c->engine == 2) {
         CHK(tiled_build(c));
         // the packed by-locus CSC (8 B per entry: 16 GB at 2e9 entries) is only streamed by engine 1; engine 2 has built
@@ -576,7 +614,7 @@ cellector_status cellector_ingest_finish(cellector_ctx *c, uint64_t min_alt, uin
         dev_free(c->csc_ent);
     }
     if (timing) fprintf(stderr, "[timing]   tiled layouts           %8.3f s\n", lap_s(&t));
-    dev_cache_trim();  // the ingest's big temporaries are done: hand the cached blocks back
+    dev_cache_trim(c->device);  // the ingest's big temporaries are done: hand this device's cached blocks back
     c->state = cellector_ctx::ST_READY;
     c->em_phase = 0; c->iteration = 0; c->have_iter = false; c->n_excluded_global = 0;
     return CELLECTOR_OK;

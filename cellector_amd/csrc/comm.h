@@ -61,4 +61,5 @@ int comm_allgather_slices(cellector_ctx *c, double *buf, uint64_t per);
 int comm_rccl_unique_id(void *out128, const char **err);
 int comm_rccl_init_rank(cellector_ctx *c, const void *id128, int n, int rank);
 int comm_rccl_init_all(cellector_ctx **shards, int n, const int *devices);
+void comm_rccl_abort(cellector_ctx *c);  // frees the communicator: drop c->comm.nccl afterwards
 void comm_destroy(cellector_ctx *c);

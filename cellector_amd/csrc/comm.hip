@@ -16,6 +16,7 @@ struct Rccl {
     ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
     ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
@@ -45,6 +46,7 @@ bool rccl_load()
     SYM(CommInitRank, "ncclCommInitRank");
     SYM(CommInitAll, "ncclCommInitAll");
     SYM(CommDestroy, "ncclCommDestroy");
+    SYM(CommAbort, "ncclCommAbort");
     SYM(AllReduce, "ncclAllReduce");
     SYM(AllGather, "ncclAllGather");
     SYM(GetErrorString, "ncclGetErrorString");
@@ -108,6 +110,14 @@ int comm_rccl_init_all(cellector_ctx **shards, int n, const int *devices)
         shards[r]->comm.nccl = comms[(size_t)r];
     }
     return (int)CELLECTOR_OK;
+}
+
+// A shard of a multi-device ctx has failed: abort every shard's communicator, so that the peers' pending and future
+// collectives return instead of waiting for the rank that will never join them.  ncclCommAbort frees the communicator: the
+// caller drops the handles once every worker is back (multi.cpp, run_all).
+void comm_rccl_abort(cellector_ctx *c)
+{
+    if (c->comm.nccl && g_rccl.so) (void)g_rccl.CommAbort((ncclComm_t)c->comm.nccl);
 }
 
 void comm_destroy(cellector_ctx *c)

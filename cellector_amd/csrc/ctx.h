@@ -25,7 +25,7 @@
 enum { LB_CONTRIB_MIN = 0, LB_CONTRIB_MAJ = 1, LB_CELLS_MIN = 2, LB_ALT_MIN = 3, LB_REF_MIN = 4, LB_PLANES = 5 };
 enum { LC_N_NEW = 0, LC_N_RESCUED = 1, LC_N_EXCLUDED = 2, LC_N_NEAR = 3 /* cells within the near-tie band of the threshold */,
        LC_COUNTERS = 8 };
-#define CELLECTOR_NEAR_TIE_REL 1e-9  // |norm - thr| <= this * max(1, |thr|) counts as a near-tie (cellector_iter_summary)
+#define CELLECTOR_NEAR_TIE_REL 1e-9  // |norm - thr| <= band * max(1, |thr|) counts as a near-tie (cellector_iter_summary); the band's floor
 // PASS1 exchange buffer layout (f64): 5 planes of total_loci
 enum { P1_CELLS_REF = 0, P1_CELLS_ALT = 1, P1_SUM_REF = 2, P1_SUM_ALT = 3, P1_ENTRIES = 4, P1_PLANES = 5 };
 
@@ -63,6 +63,7 @@ struct cellector_ctx {
 
     // options
     bool compute_expected = true;
+    bool ref_arith = false;  // option ref_arith (engine 1): evaluate stats.rs:41-53 with ln_gamma differences, the reference's own rounding
     int64_t parse_window_opt = 0;  // option parse_window: 0 = whole file below 1 GB, 256 MB windows above; else the window in bytes
     int tile_groups_opt = 0;  // option tile_groups: 0 = chosen per matrix (tiled_setup), else forced (multiple of 8)
     // option sharded_select: a ctx with a communicator exchanges digit histograms (1) or all-gathers NORM (0); -1 = by the
@@ -71,6 +72,7 @@ struct cellector_ctx {
     bool norm_zero = true;  // option: clear the other shards' slices of NORM before the cell pass (needed by a sum exchange)
     int timing = 0;  // 0 off, 1 every timed region, 2 only the dominant kernel of the engine
     bool keep_coo = true;
+    double near_rel = CELLECTOR_NEAR_TIE_REL;  // near-tie band of this matrix, relative to max(1, |threshold|) (cellector_ingest_finish)
     int synth_continue_pct = 30;  // option synth_continue_pct: the synthetic generator's n = 1 + Geometric(1 - pct/100)
 
     // shard
@@ -230,7 +232,7 @@ cellector_status ctx_fail(const cellector_ctx *c, cellector_status s, const char
 // and handed out again to requests of at least half their size; dev_cache_trim() returns them to the driver.
 hipError_t dev_cache_malloc(void **p, size_t bytes);
 void dev_cache_free(void *p);
-void dev_cache_trim();
+void dev_cache_trim(int device = -1);  // -1: the cached blocks of every device
 void dev_cache_park(void *p, size_t bytes, int device);  // a fresh, unused hipMalloc block for later requests of its size
 
 template <typename T>
@@ -249,6 +251,18 @@ static inline void dev_free(T *&p)
 {
     if (p) dev_cache_free((void *)p);
     p = nullptr;
+}
+
+// Device-to-device copy between two shards (one device, or peers) on the RECEIVING shard's stream, complete on return.  (On the
+// null stream such a copy may return before it is done, and the shards' non-blocking streams do not order against that stream:
+// a kernel launched right behind it could read stale bytes.)
+static inline hipError_t dev_copy_sync(hipStream_t st, void *dst, int dst_dev, const void *src, int src_dev, size_t bytes)
+{
+    if (!bytes) return hipSuccess;
+    hipError_t e = dst_dev == src_dev ? hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, st)
+                                      : hipMemcpyPeerAsync(dst, dst_dev, src, src_dev, bytes, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    return e;
 }
 
 // ---- timing -----------------------------------------------------------------------------------

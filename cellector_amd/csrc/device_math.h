@@ -71,6 +71,28 @@ __device__ __forceinline__ double dm_log_bb_pmf(const double *lf, double alpha, 
     return dm_ln_choose(lf, a, r) + dm_log_beta_ratio(alpha, beta, a, r);
 }
 
+// ---- option ref_arith (engine 1): the reference's OWN arithmetic, operation for operation ---------------------------------
+// log_beta_calc (stats.rs:48-53) and log_beta_binomial_pmf (stats.rs:41-46) with statrs' Lanczos ln_gamma in the reference's
+// association order: (lnGamma(a) + lnGamma(b)) - lnGamma(a + b), then (lnC + numerator) - denominator.  Reproduces the
+// reference's cancellation error (~eps * lnGamma(alpha + beta), i.e. 1e-11 .. 1e-9 per entry at alpha + beta of 1e4 .. 1e6)
+// instead of avoiding it; what is left between this and the reference's bits is the last ulp of log() in the two maths
+// libraries (the product form above is the default because it is more accurate and an order of magnitude cheaper).
+// Arguments below 0.5 (statrs' reflection branch) do not occur: alpha, beta >= 1 by construction (main.rs:598-611).
+__device__ inline double dm_log_beta_calc_ref(double a, double b)
+{
+    const double lga = dm_ln_gamma(a);
+    const double lgb = dm_ln_gamma(b);
+    const double lgab = dm_ln_gamma(a + b);
+    return lga + lgb - lgab;
+}
+__device__ inline double dm_log_bb_pmf_ref(const double *lf, double alpha, double beta, uint32_t a, uint32_t r)
+{
+    const double lnc = dm_ln_choose(lf, a, r);
+    const double num = dm_log_beta_calc_ref((double)a + alpha, (double)r + beta);
+    const double den = dm_log_beta_calc_ref(alpha, beta);
+    return lnc + num - den;
+}
+
 // stats.rs:35-39
 __device__ __forceinline__ double dm_logsumexp(double x, double y)
 {
@@ -121,4 +143,12 @@ __device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v)
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
     return v;
+}
+
+// expected_log_beta_binomial_pmf with the reference's arithmetic (stats.rs:8-22): the log-space fold over all n + 1 pmfs
+__device__ inline double dm_expected_log_pmf_ref(const double *lf, double alpha, double beta, uint32_t n)
+{
+    double e = 2.0 * dm_log_bb_pmf_ref(lf, alpha, beta, 0u, n);
+    for (uint32_t k = 1; k <= n; ++k) e = dm_logsumexp(e, 2.0 * dm_log_bb_pmf_ref(lf, alpha, beta, k, n - k));
+    return e;
 }

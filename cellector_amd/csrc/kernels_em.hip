@@ -50,7 +50,7 @@ __global__ void k_ab_from_arrays(uint64_t L, const double *__restrict__ alpha, c
 // One wave per cell row; lanes stride the row (coalesced 512 B per wave-load), gather (alpha,beta) of the
 // entry's locus, accumulate log-pmf / expected-log-pmf / used-locus count, wave shuffle reduction.
 // ---------------------------------------------------------------------------------------------------
-template <bool EXPECTED>
+template <bool EXPECTED, bool REF /*option ref_arith: the reference's ln_gamma arithmetic*/>
 __global__ __launch_bounds__(BLOCK) void k_cell_ll(uint64_t n_rows, const uint64_t *__restrict__ row_ptr,
                                                    const uint64_t *__restrict__ ent,
                                                    const double2 *__restrict__ ab,
@@ -73,8 +73,8 @@ __global__ __launch_bounds__(BLOCK) void k_cell_ll(uint64_t n_rows, const uint64
             const double2 p = ab[ENT_IDX(en)];
             if (p.x >= 0.0) {
                 const uint32_t a = ENT_ALT(en), r = ENT_REF(en);
-                s += dm_log_bb_pmf(lf, p.x, p.y, a, r);
-                if (EXPECTED) e += dm_expected_log_pmf(lf, p.x, p.y, a + r);
+                s += REF ? dm_log_bb_pmf_ref(lf, p.x, p.y, a, r) : dm_log_bb_pmf(lf, p.x, p.y, a, r);
+                if (EXPECTED) e += REF ? dm_expected_log_pmf_ref(lf, p.x, p.y, a + r) : dm_expected_log_pmf(lf, p.x, p.y, a + r);
                 cnt++;
             }
         }
@@ -98,7 +98,8 @@ __global__ __launch_bounds__(BLOCK) void k_cell_ll(uint64_t n_rows, const uint64
 __global__ __launch_bounds__(FLAG_THREADS) void k_flag(uint64_t n, const double *__restrict__ norm, const double *__restrict__ d_thr,
                                                        const uint8_t *__restrict__ old_flags, uint8_t *__restrict__ new_flags,
                                                        double *__restrict__ counters, uint32_t *__restrict__ minlist /*may be null*/,
-                                                       uint32_t *__restrict__ n_min, uint32_t *__restrict__ flag_bits /*with minlist*/)
+                                                       uint32_t *__restrict__ n_min, uint32_t *__restrict__ flag_bits /*with minlist*/,
+                                                       double near_rel)
 {
     __shared__ uint32_t s_wave[FLAG_THREADS / 64];
     __shared__ uint32_t s_base;
@@ -108,9 +109,10 @@ __global__ __launch_bounds__(FLAG_THREADS) void k_flag(uint64_t n, const double 
     const uint64_t beg = min(n, (uint64_t)blockIdx.x * span), end = min(n, beg + span);
     uint32_t c_new = 0, c_res = 0, c_exc = 0, c_near = 0;
     // near-ties: the device arithmetic is a reformulation of the reference's (device_math.h), ~1e-11 away from it on a
-    // normalised log-likelihood; a cell this close to the threshold could fall on the other side of main.rs:330-332's
-    // strict `<` in the reference.  Counted, reported in the summary, never acted upon.
-    const double near_tol = CELLECTOR_NEAR_TIE_REL * fmax(1.0, fabs(thr));
+    // normalised log-likelihood at vartrix-like depth (more on deep loci: the band follows the matrix, cellector_ingest_finish);
+    // a cell this close to the threshold could fall on the other side of main.rs:330-332's strict `<` in the reference.
+    // Counted, reported in the summary, never acted upon.
+    const double near_tol = near_rel * fmax(1.0, fabs(thr));
     for (uint64_t i = beg + threadIdx.x; i < end; i += FLAG_THREADS) {
         const double v = norm[i];
         const bool nf = v < thr;
@@ -174,6 +176,7 @@ __global__ __launch_bounds__(FLAG_THREADS) void k_flag(uint64_t n, const double 
 // masked loci included (they feed init_alpha_betas and the posterior alpha/betas, which ignore the mask);
 // contributions and cell counts are zero for masked loci (a masked locus has no PMFData, main.rs:556).
 // ---------------------------------------------------------------------------------------------------
+template <bool REF>
 __global__ __launch_bounds__(BLOCK) void k_locus_stats(uint64_t L, const uint64_t *__restrict__ col_ptr,
                                                        const uint64_t *__restrict__ ent,
                                                        const double2 *__restrict__ ab,
@@ -200,7 +203,7 @@ __global__ __launch_bounds__(BLOCK) void k_locus_stats(uint64_t L, const uint64_
             const bool minority = flags[ENT_IDX(en)] != 0;
             if (minority) { amin += a; rmin += r; }
             if (live) {
-                const double lp = dm_log_bb_pmf(lf, p.x, p.y, a, r);
+                const double lp = REF ? dm_log_bb_pmf_ref(lf, p.x, p.y, a, r) : dm_log_bb_pmf(lf, p.x, p.y, a, r);
                 if (minority) { cmin += lp; nmin++; } else cmaj += lp;
             }
         }
@@ -261,6 +264,7 @@ __global__ void k_ab_posterior(uint64_t L, const double *__restrict__ s_alt, con
     o[0] = a_min; o[1] = b_min; o[2] = a_maj; o[3] = b_maj; o[4] = a_dbl; o[5] = b_dbl; o[6] = 0.0; o[7] = 0.0;
 }
 
+template <bool REF>
 __global__ __launch_bounds__(BLOCK) void k_posterior(uint64_t n_rows, const uint64_t *__restrict__ row_ptr,
                                                      const uint64_t *__restrict__ ent,
                                                      const double *__restrict__ ab6,
@@ -281,10 +285,16 @@ __global__ __launch_bounds__(BLOCK) void k_posterior(uint64_t n_rows, const uint
             const double2 *p = reinterpret_cast<const double2 *>(ab6 + 8 * (uint64_t)ENT_IDX(en));
             const double2 pmin = p[0], pmaj = p[1], pdbl = p[2];
             const uint32_t a = ENT_ALT(en), r = ENT_REF(en);
-            const double lnc = dm_ln_choose(lf, a, r);
-            s_min += lnc + dm_log_beta_ratio(pmin.x, pmin.y, a, r);
-            s_maj += lnc + dm_log_beta_ratio(pmaj.x, pmaj.y, a, r);
-            s_dbl += lnc + dm_log_beta_ratio(pdbl.x, pdbl.y, a, r);
+            if (REF) {
+                s_min += dm_log_bb_pmf_ref(lf, pmin.x, pmin.y, a, r);
+                s_maj += dm_log_bb_pmf_ref(lf, pmaj.x, pmaj.y, a, r);
+                s_dbl += dm_log_bb_pmf_ref(lf, pdbl.x, pdbl.y, a, r);
+            } else {
+                const double lnc = dm_ln_choose(lf, a, r);
+                s_min += lnc + dm_log_beta_ratio(pmin.x, pmin.y, a, r);
+                s_maj += lnc + dm_log_beta_ratio(pmaj.x, pmaj.y, a, r);
+                s_dbl += lnc + dm_log_beta_ratio(pdbl.x, pdbl.y, a, r);
+            }
         }
         s_min = wave_sum(s_min);
         s_maj = wave_sum(s_maj);
@@ -404,12 +414,15 @@ cellector_status launch_cell_ll(cellector_ctx *c, const double2 *ab, double *nor
     // one wave per row, grid-stride beyond 2^20 blocks
     const unsigned grid = grid_for(c->nloc, WAVES_PER_BLOCK, 1u << 20);
     timer_begin(c, CELLECTOR_K_CELL_LL);
-    if (c->compute_expected)
-        hipLaunchKernelGGL(k_cell_ll<true>, dim3(grid), dim3(BLOCK), 0, c->stream, c->nloc, c->csr_ptr, c->csr_ent,
-                           ab, c->lf, c->ll, c->ell, c->nloci, norm_out);
-    else
-        hipLaunchKernelGGL(k_cell_ll<false>, dim3(grid), dim3(BLOCK), 0, c->stream, c->nloc, c->csr_ptr, c->csr_ent,
-                           ab, c->lf, c->ll, c->ell, c->nloci, norm_out);
+#define LAUNCH_CELL(E, R)                                                                                           \
+    hipLaunchKernelGGL((k_cell_ll<E, R>), dim3(grid), dim3(BLOCK), 0, c->stream, c->nloc, c->csr_ptr, c->csr_ent, ab, \
+                       c->lf, c->ll, c->ell, c->nloci, norm_out)
+    if (c->compute_expected) {
+        if (c->ref_arith) LAUNCH_CELL(true, true); else LAUNCH_CELL(true, false);
+    } else {
+        if (c->ref_arith) LAUNCH_CELL(false, true); else LAUNCH_CELL(false, false);
+    }
+#undef LAUNCH_CELL
     timer_end(c, CELLECTOR_K_CELL_LL);
     HIPCHK(c, hipGetLastError());
     return CELLECTOR_OK;
@@ -420,7 +433,7 @@ cellector_status launch_flag(cellector_ctx *c, const double *d_thr)
     if (c->nloc == 0) return CELLECTOR_OK;
     hipLaunchKernelGGL(k_flag, dim3(grid_for(c->nloc, FLAG_THREADS * 4, 256)), dim3(FLAG_THREADS), 0, c->stream, c->nloc,
                        c->x_norm + c->cell_begin, d_thr, c->flags, c->flags_new, c->x_locus + LB_PLANES * c->L,
-                       c->tiled_ready ? c->minlist : (uint32_t *)nullptr, c->d_counters + DC_N_MIN, c->flag_bits);
+                       c->tiled_ready ? c->minlist : (uint32_t *)nullptr, c->d_counters + DC_N_MIN, c->flag_bits, c->near_rel);
     HIPCHK(c, hipGetLastError());
     return CELLECTOR_OK;
 }
@@ -430,8 +443,12 @@ cellector_status launch_locus_stats(cellector_ctx *c)
     if (c->L == 0) return CELLECTOR_OK;
     const unsigned grid = grid_for(c->L, WAVES_PER_BLOCK, 1u << 20);
     timer_begin(c, CELLECTOR_K_LOCUS_STATS);
-    hipLaunchKernelGGL(k_locus_stats, dim3(grid), dim3(BLOCK), 0, c->stream, c->L, c->csc_ptr, c->csc_ent, c->ab,
-                       c->flags_new, c->lf, c->x_locus);
+    if (c->ref_arith)
+        hipLaunchKernelGGL(k_locus_stats<true>, dim3(grid), dim3(BLOCK), 0, c->stream, c->L, c->csc_ptr, c->csc_ent, c->ab,
+                           c->flags_new, c->lf, c->x_locus);
+    else
+        hipLaunchKernelGGL(k_locus_stats<false>, dim3(grid), dim3(BLOCK), 0, c->stream, c->L, c->csc_ptr, c->csc_ent, c->ab,
+                           c->flags_new, c->lf, c->x_locus);
     timer_end(c, CELLECTOR_K_LOCUS_STATS);
     HIPCHK(c, hipGetLastError());
     return CELLECTOR_OK;
@@ -464,8 +481,12 @@ cellector_status launch_posteriors(cellector_ctx *c, double mf0, double lp_min, 
     if (c->nloc == 0) return CELLECTOR_OK;
     const unsigned grid = grid_for(c->nloc, WAVES_PER_BLOCK, 1u << 20);
     timer_begin(c, CELLECTOR_K_POSTERIOR);
-    hipLaunchKernelGGL(k_posterior, dim3(grid), dim3(BLOCK), 0, c->stream, c->nloc, c->csr_ptr, c->csr_ent, c->ab6,
-                       c->lf, lp_min, lp_maj, lp_dbl, c->post);
+    if (c->ref_arith)
+        hipLaunchKernelGGL(k_posterior<true>, dim3(grid), dim3(BLOCK), 0, c->stream, c->nloc, c->csr_ptr, c->csr_ent, c->ab6,
+                           c->lf, lp_min, lp_maj, lp_dbl, c->post);
+    else
+        hipLaunchKernelGGL(k_posterior<false>, dim3(grid), dim3(BLOCK), 0, c->stream, c->nloc, c->csr_ptr, c->csr_ent, c->ab6,
+                           c->lf, lp_min, lp_maj, lp_dbl, c->post);
     timer_end(c, CELLECTOR_K_POSTERIOR);
     HIPCHK(c, hipGetLastError());
     return CELLECTOR_OK;

@@ -737,7 +737,7 @@ bool mtx_input_windowed(const MtxInput *in, int64_t parse_window_opt)
 static cellector_status copy_between(cellector_ctx *c, void *dst, int dst_dev, const void *src, int src_dev, size_t bytes)
 {
     if (!bytes) return CELLECTOR_OK;
-    const hipError_t e = dst_dev == src_dev ? hipMemcpy(dst, src, bytes, hipMemcpyDeviceToDevice) : hipMemcpyPeer(dst, dst_dev, src, src_dev, bytes);
+    const hipError_t e = dev_copy_sync(c->stream, dst, dst_dev, src, src_dev, bytes);  // (c = the receiving shard, its device current)
     if (e != hipSuccess) return ctx_fail(c, CELLECTOR_EDEVICE, "copy between shards failed: %s", hipGetErrorString(e));
     return CELLECTOR_OK;
 }
@@ -775,7 +775,10 @@ cellector_status ingest_stage_mtx_split(cellector_ctx *c, MtxInput *in, MtxSplit
             return ctx_fail(c, CELLECTOR_ECOMM, "another shard of this ctx failed during the ingest");   \
         }                                                                                                \
     } while (0)
-    HIPCHK(c, hipSetDevice(c->device));
+    if (hipSetDevice(c->device) != hipSuccess) {  // (through the barrier group like every other failure: the peers must not wait)
+        S->bar->fail();
+        return ctx_fail(c, CELLECTOR_EDEVICE, "hipSetDevice(%d) failed", c->device);
+    }
     S->device[rank] = c->device;
     const bool timing = rank == 0 && getenv("CELLECTOR_TIMING") != nullptr;  // phase wall times of shard 0 on stderr
     auto t_prev = std::chrono::steady_clock::now();
@@ -846,7 +849,7 @@ cellector_status ingest_stage_mtx_split(cellector_ctx *c, MtxInput *in, MtxSplit
     auto g_lo = [&](const uint64_t *b, int k) -> uint64_t { return k == 0 ? (uint64_t)0 : b[k] + 1; };
     auto g_hi = [&](const uint64_t *b, int k) -> uint64_t { return std::min<uint64_t>(nlines, b[k + 1] + 1); };  // exclusive
     const uint64_t glo = std::min(g_lo(abase, rank), nlines), ghi = std::max(glo, g_hi(abase, rank));
-    const uint64_t count = ghi - glo, lo = glo - abase[rank];
+    const uint64_t count = ghi - glo, lo = count ? glo - abase[rank] : 0;  // (a rank whose alt range lies beyond a shorter ref file holds nothing)
     SCHK(dev_alloc(c, &rk, ma + 2));
     for (int k = 0; k < n; k++) {
         const uint64_t s0 = std::max(glo, g_lo(rbase, k)), s1 = std::min(ghi, g_hi(rbase, k));
@@ -1045,7 +1048,7 @@ cellector_status ingest_stage_mtx_device(cellector_ctx *c, MtxInput *in, cellect
         (void)hipSetDevice(c->device);
         if (st_a == CELLECTOR_OK && st_r != CELLECTOR_OK) st_a = ctx_fail(c, st_r, "%s", helper->err.c_str());
         if (st_a == CELLECTOR_OK) st_a = dev_alloc(c, &r, n_r);
-        if (st_a == CELLECTOR_OK && n_r && hipMemcpyPeer(r, c->device, r_h, helper->device, n_r * sizeof(uint32_t)) != hipSuccess)
+        if (st_a == CELLECTOR_OK && n_r && dev_copy_sync(c->stream, r, c->device, r_h, helper->device, n_r * sizeof(uint32_t)) != hipSuccess)
             st_a = ctx_fail(c, CELLECTOR_EDEVICE, "peer copy of the ref counts failed: %s", hipGetErrorString(hipGetLastError()));
         if (st_a == CELLECTOR_OK &&
             (hipMemcpyAsync(bad + 1, &bad_r, sizeof bad_r, hipMemcpyHostToDevice, c->stream) != hipSuccess ||

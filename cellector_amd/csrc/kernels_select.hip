@@ -672,10 +672,8 @@ cellector_status select_threshold_sharded(cellector_ctx *c, const double *keys, 
     auto clampr = [n](int64_t r) -> uint64_t { return r < 0 ? 0 : ((uint64_t)r >= n ? n - 1 : (uint64_t)r); };
     const uint64_t ranks[SEL_T] = {k ? k - 1 : 0, k, clampr(q.hf1 - 1), clampr(q.hf1), clampr(q.hf3 - 1), clampr(q.hf3)};
     constexpr uint64_t HW = (uint64_t)SEL_T * SELD_NB;  // histogram words of a level
-    if (!c->seld_hist) {
-        CHK(dev_alloc(c, &c->seld_hist, SELD_LEVELS * HW));
-        CHK(dev_alloc(c, &c->seld_state, (uint64_t)(SELD_LEVELS + 1) * 2 * SEL_T));
-    }
+    if (!c->seld_hist) CHK(dev_alloc(c, &c->seld_hist, SELD_LEVELS * HW));
+    if (!c->seld_state) CHK(dev_alloc(c, &c->seld_state, (uint64_t)(SELD_LEVELS + 1) * 2 * SEL_T));
     sel_ranks_t r;
     for (int t = 0; t < SEL_T; t++) r.r[t] = ranks[t];
     timer_begin(c, CELLECTOR_K_SELECT);

@@ -28,6 +28,7 @@ struct MultiCtx {
     int pending = 0;
     bool stop = false;
     std::vector<cellector_status> result;
+    bool comm_aborted = false;  // (under mu) a shard failed in RCCL mode: the communicators are gone, the ctx takes no more sharded work
 };
 
 static void worker_main(MultiCtx *m, int rank)
@@ -56,6 +57,14 @@ static void worker_main(MultiCtx *m, int rank)
         }
         const cellector_status st = fn(c, rank);
         if (st != CELLECTOR_OK && m->use_local) m->local.fail();  // (the other shards may be waiting for this one)
+        if (st != CELLECTOR_OK && !m->use_local && m->shards.size() > 1) {
+            // RCCL: the peers would sit in a collective (or in the stream wait behind it) forever — abort the communicators
+            std::lock_guard<std::mutex> lk(m->mu);
+            if (!m->comm_aborted) {
+                m->comm_aborted = true;
+                for (cellector_ctx *s : m->shards) comm_rccl_abort(s);
+            }
+        }
         {
             std::lock_guard<std::mutex> lk(m->mu);
             m->result[(size_t)rank] = st;
@@ -79,6 +88,8 @@ static cellector_status run_all(const cellector_ctx *root, std::function<cellect
         std::unique_lock<std::mutex> lk(m->mu);
         m->cv_done.wait(lk, [&] { return m->pending == 0; });
     }
+    if (m->comm_aborted)  // (every worker is back: nobody reads the handles any more; ncclCommAbort has freed them)
+        for (cellector_ctx *s : m->shards) s->comm.nccl = nullptr;
     {   // every worker is back: a failure that released the others from a barrier must not poison the next call
         std::lock_guard<std::mutex> lk(m->local.mu);
         m->local.failed = false;
@@ -282,8 +293,10 @@ cellector_status multi_ingest_mtx(cellector_ctx *root, const char *alt_path, con
             if (st == CELLECTOR_OK) st = dev_alloc(s, &qa, cnt);
             if (st == CELLECTOR_OK) st = dev_alloc(s, &qr, cnt);
             if (st == CELLECTOR_OK && cnt &&
-                (hipMemcpyPeer(ql, s->device, pl, all.device, cnt * 4) != hipSuccess || hipMemcpyPeer(qc, s->device, pc, all.device, cnt * 4) != hipSuccess ||
-                 hipMemcpyPeer(qa, s->device, pa, all.device, cnt * 2) != hipSuccess || hipMemcpyPeer(qr, s->device, pr, all.device, cnt * 2) != hipSuccess))
+                (dev_copy_sync(s->stream, ql, s->device, pl, all.device, cnt * 4) != hipSuccess ||
+                 dev_copy_sync(s->stream, qc, s->device, pc, all.device, cnt * 4) != hipSuccess ||
+                 dev_copy_sync(s->stream, qa, s->device, pa, all.device, cnt * 2) != hipSuccess ||
+                 dev_copy_sync(s->stream, qr, s->device, pr, all.device, cnt * 2) != hipSuccess))
                 st = ctx_fail(s, CELLECTOR_EDEVICE, "peer copy of the shard's entries failed: %s", hipGetErrorString(hipGetLastError()));
             (void)hipSetDevice(all.device);
             dev_free(pl); dev_free(pc); dev_free(pa); dev_free(pr);

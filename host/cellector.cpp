@@ -169,7 +169,8 @@ struct Params {
     double posterior_threshold = 0.999, interquartile_range_multiple = 5.0;
     std::optional<double> expected_percent_minority;  // parsed, never used (quirk Q2)
     int device = -1;                                   // extension: ONE GPU to run on
-    std::vector<int> devices;                          // extension: the GPUs to shard the cells over (default: automatic)
+    std::vector<int> devices;                          // extension: the GPUs to shard the cells over (default: GPU 0)
+    bool devices_auto = false;                         // --devices auto: as many visible GPUs as the input can feed
 };
 
 const char *USAGE =
@@ -191,8 +192,8 @@ const char *USAGE =
     "    -v, --vcf <vcf>                                                    vcf associated with alt.mtx and ref.mtx\n"
     "        --device <n>                                                   run on this one GPU (not in the reference)\n"
     "        --devices <a,b,...>                                            GPUs to shard the cells over, RCCL exchanges between them (not in\n"
-    "                                                                       the reference; default: all visible GPUs for inputs of several GB\n"
-    "                                                                       per GPU, else GPU 0; a GPU listed twice = two logical shards on it)\n";
+    "                                                                       the reference; default: GPU 0; `auto`: one visible GPU per 4 GB of\n"
+    "                                                                       alt.mtx text; a GPU listed twice = two logical shards on it)\n";
 
 uint64_t parse_usize(const std::string &name, const std::string &s)
 {
@@ -257,8 +258,11 @@ Params load_params(int argc, char **argv)
     if (got.count("expected_percent_minority")) p.expected_percent_minority = parse_f64("expected_percent_minority", got["expected_percent_minority"]);
     if (got.count("min_loci_for_assignment")) p.min_loci_used = parse_usize("min_loci_for_assignment", got["min_loci_for_assignment"]);
     if (got.count("device")) p.device = (int)parse_usize("device", got["device"]);
-    if (got.count("devices"))
-        for (const std::string &t : split(got["devices"], ',')) p.devices.push_back((int)parse_usize("devices", t));
+    if (got.count("devices")) {
+        if (got["devices"] == "auto") p.devices_auto = true;
+        else
+            for (const std::string &t : split(got["devices"], ',')) p.devices.push_back((int)parse_usize("devices", t));
+    }
     if (got.count("device") && got.count("devices")) die(1, "error: The argument '--device <n>' cannot be used with '--devices <a,b,...>'");
     return p;
 }
@@ -383,12 +387,15 @@ int main(int argc, char **argv)
         t_prev = now;
     };
     // load_cell_data (load_data.rs:134-181) on the device
-    // Which GPUs: --device n / --devices a,b,... as given; else all visible GPUs when the input is large enough to feed them
-    // (one GPU per 4 GB of alt.mtx text, i.e. >= 1.3e8 entries each: below that the per-iteration exchanges and the
-    // communicator set-up cost more than the extra GPUs save), else GPU 0.  cellector_pipeline.py:223-226 passes neither flag.
+    // Which GPUs: --device n / --devices a,b,... as given; neither (cellector_pipeline.py:223-226 passes neither flag): GPU 0 —
+    // the multi-GPU path over RCCL is opt-in until it has run on a multi-GPU node (README).  --devices auto: all visible GPUs
+    // when the input is large enough to feed them (one GPU per 4 GB of alt.mtx text, i.e. >= 1.3e8 entries each: below that
+    // the per-iteration exchanges and the communicator set-up cost more than the extra GPUs save); should the multi-device
+    // ctx fail to come up there, the run falls back to GPU 0 with a note on stderr.
     Ctx g;
     std::vector<int> devices = params.devices;
     if (devices.empty() && params.device >= 0) devices.push_back(params.device);
+    if (devices.empty() && !params.devices_auto) devices.push_back(0);
     if (devices.empty()) {
         int visible = 0;
         (void)cellector_device_count(&visible);
@@ -401,7 +408,13 @@ int main(int argc, char **argv)
         const int n = (int)std::max<uint64_t>(1, std::min<uint64_t>(want, (uint64_t)std::min(visible, 16)));
         for (int i = 0; i < n; i++) devices.push_back(i);
     }
-    if (cellector_create_multi(&g.c, devices.data(), (int)devices.size()) != CELLECTOR_OK)
+    cellector_status cst = cellector_create_multi(&g.c, devices.data(), (int)devices.size());
+    if (cst != CELLECTOR_OK && params.devices_auto && devices.size() > 1) {
+        fprintf(stderr, "cellector: the %zu-GPU context did not come up (status %d); running on GPU 0\n", devices.size(), (int)cst);
+        devices.assign(1, 0);
+        cst = cellector_create_multi(&g.c, devices.data(), 1);
+    }
+    if (cst != CELLECTOR_OK)
         die(EXIT_PANIC, "cellector: no usable MI355X device (asked for " + std::to_string(devices.size()) + ", first: " +
                             std::to_string(devices[0]) + "; there is no CPU fallback)");
     if (const char *e = getenv("CELLECTOR_ENGINE")) g.ck(cellector_set_option(g.c, "engine", atoi(e)), "engine");

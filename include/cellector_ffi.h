@@ -178,11 +178,14 @@ typedef struct {
     uint64_t n_excluded;               /* |new exclusion set| over all shards                    */
     uint64_t n_loci_filtered;          /* loci newly masked by the -80 filter (main.rs:444-447)  */
     double median, iqr, threshold;     /* main.rs:325-329                                        */
-    /* Not in the reference: cells (all shards) with |normalised LL - threshold| <= 1e-9 * max(1, |threshold|).
-     * The device evaluates log_beta_binomial_pmf as an exact product ratio, ~1e-11 away from the reference's
-     * ln_gamma differences (stats.rs:41-53) on a normalised LL; such a cell could fall on the other side of
-     * main.rs:330-332's strict `<` in the reference.  Non-zero = the bit-identical-assignment claim does not
-     * cover those cells of this iteration.  host/cellector prints one stderr warning. */
+    /* Not in the reference: cells (all shards) with |normalised LL - threshold| <= band * max(1, |threshold|),
+     * band = max(1e-9, 8 * 2^-52 * lgamma(max over the used loci of S_alt + S_ref + 2)).
+     * The device evaluates log_beta_binomial_pmf as an exact product ratio; the reference's ln_gamma differences
+     * (stats.rs:41-53) carry ~2^-52 * lnGamma(alpha + beta) of cancellation error per term — 1e-11 on a normalised
+     * LL at vartrix-like depth (alpha + beta ~ 1e4: the band is its 1e-9 floor), 1e-8 at alpha + beta ~ 1e6 — so such
+     * a cell could fall on the other side of main.rs:330-332's strict `<` in the reference.  Non-zero = the
+     * bit-identical-assignment claim does not cover those cells of this iteration.  host/cellector prints one
+     * stderr warning.  (Option ref_arith, engine 1, evaluates the reference's own formula instead.) */
     uint64_t n_near_threshold;
 } cellector_iter_summary;
 
