@@ -405,11 +405,47 @@ cellector_status cellector_set_option(cellector_ctx *c, const char *key, int64_t
     return CELLECTOR_OK;
 }
 
+cellector_status cellector_set_partition(cellector_ctx *c, const uint64_t *bounds, int n_bounds)
+{
+    if (!c) return CELLECTOR_EINVAL;
+    if (c->multi) return multi_set_partition(c, bounds, n_bounds);
+    REQUIRE(c, comm_active(c->comm), "set_partition: the ctx has no communicator (a single shard takes cellector_set_shard)");
+    REQUIRE(c, c->state == cellector_ctx::ST_EMPTY, "set_partition must precede the ingest");
+    if (!bounds || n_bounds == 0) {  // back to the canonical equal ranges
+        c->comm.has_bounds = false;
+        return CELLECTOR_OK;
+    }
+    REQUIRE(c, n_bounds == c->comm.n + 1, "set_partition: one boundary more than there are ranks");
+    REQUIRE(c, bounds[0] == 0, "set_partition: the first range starts at cell 0");
+    for (int r = 0; r < c->comm.n; r++) REQUIRE(c, bounds[r] <= bounds[r + 1], "set_partition: boundaries must not decrease");
+    for (int r = 0; r <= c->comm.n; r++) c->comm.bounds[r] = bounds[r];
+    c->comm.has_bounds = true;
+    return CELLECTOR_OK;
+}
+
+cellector_status cellector_partition(const cellector_ctx *c, uint64_t *bounds_out, int *n_ranks)
+{
+    if (!c) return CELLECTOR_EINVAL;
+    if (c->multi) c = multi_shard0(c);
+    if (n_ranks) *n_ranks = c->comm.n;
+    if (bounds_out) {
+        REQUIRE(c, c->state != cellector_ctx::ST_EMPTY, "partition: nothing loaded yet");
+        for (int r = 0; r < c->comm.n; r++) {
+            uint64_t b, e;
+            comm_range(c->comm, c->total_cells, r, &b, &e);
+            bounds_out[r] = b;
+            bounds_out[r + 1] = e;
+        }
+        if (c->comm.n == 1) { bounds_out[0] = c->cell_begin; bounds_out[1] = c->cell_end; }
+    }
+    return CELLECTOR_OK;
+}
+
 cellector_status cellector_set_shard(cellector_ctx *c, uint64_t b, uint64_t e)
 {
     if (!c) return CELLECTOR_EINVAL;
     if (c->multi || comm_active(c->comm))
-        return ctx_fail(c, CELLECTOR_EINVAL, "a ctx with a communicator shards the cells itself (equal contiguous ranges by rank)");
+        return ctx_fail(c, CELLECTOR_EINVAL, "a ctx with a communicator shards the cells itself (contiguous ranges by rank: cellector_set_partition)");
     REQUIRE(c, c->state == cellector_ctx::ST_EMPTY, "set_shard must precede ingest");
     REQUIRE(c, b <= e, "empty or inverted shard range");
     c->cell_begin = b;
@@ -436,10 +472,11 @@ static cellector_status begin_ingest(cellector_ctx *c, uint64_t total_loci, uint
     if (c->ingest_all_cells) {
         c->cell_begin = 0;
         c->cell_end = total_cells;
-    } else if (comm_active(c->comm)) {  // rank r owns the r-th of n equal contiguous ranges (the NORM all-gather needs equal slots)
-        const uint64_t per = comm_cells_per_rank(total_cells, c->comm.n);
-        c->cell_begin = std::min(total_cells, (uint64_t)c->comm.rank * per);
-        c->cell_end = std::min(total_cells, c->cell_begin + per);
+    } else if (comm_active(c->comm)) {  // rank r owns the r-th contiguous range: equal ranges, or the partition it was given
+        if (c->comm.has_bounds && c->comm.bounds[c->comm.n] != total_cells)
+            return ctx_fail(c, CELLECTOR_EINVAL, "the partition covers %llu cells, the matrix has %llu",
+                            (unsigned long long)c->comm.bounds[c->comm.n], (unsigned long long)total_cells);
+        comm_range(c->comm, total_cells, c->comm.rank, &c->cell_begin, &c->cell_end);
     }
     if (c->cell_end > total_cells) c->cell_end = total_cells;
     if (c->cell_begin > c->cell_end) c->cell_begin = c->cell_end;
@@ -805,7 +842,7 @@ cellector_status cellector_em_threshold(cellector_ctx *c, double iqr_multiple)
     if (comm_active(c->comm) && comm_sharded_select(c->comm, c->sharded_select, n)) {
         CHK(select_threshold_sharded(c, c->x_norm + c->cell_begin, c->nloc, n, iqr_multiple));
     } else {
-        if (comm_active(c->comm)) CHK((cellector_status)comm_allgather_slices(c, c->x_norm, comm_cells_per_rank(n, c->comm.n)));
+        if (comm_active(c->comm)) CHK((cellector_status)comm_allgather_cells(c, c->x_norm, n));
         CHK(select_threshold(c, c->x_norm, n, iqr_multiple));
     }
     // (the counters k_flag adds to were reset by this iteration's k_alpha_beta)

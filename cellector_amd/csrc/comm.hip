@@ -1,6 +1,8 @@
 // Exchange layer of a sharded run: RCCL over xGMI, or device-side sums between logical shards that share a GPU (comm.h).
 #include <dlfcn.h>
 
+#include <algorithm>
+
 #include <rccl/rccl.h>
 
 #include "comm.h"
@@ -19,6 +21,9 @@ struct Rccl {
     ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
     ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Broadcast)(const void *, void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
     std::string why;
 };
@@ -49,6 +54,9 @@ bool rccl_load()
     SYM(CommAbort, "ncclCommAbort");
     SYM(AllReduce, "ncclAllReduce");
     SYM(AllGather, "ncclAllGather");
+    SYM(Broadcast, "ncclBroadcast");
+    SYM(GroupStart, "ncclGroupStart");
+    SYM(GroupEnd, "ncclGroupEnd");
     SYM(GetErrorString, "ncclGetErrorString");
 #undef SYM
     if (!ok) {
@@ -199,16 +207,18 @@ static int local_allreduce(cellector_ctx *c, T *buf, uint64_t count)
     return (int)CELLECTOR_OK;
 }
 
-static int local_allgather(cellector_ctx *c, double *buf, uint64_t per)
+static int local_allgather(cellector_ctx *c, double *buf, uint64_t total_cells)
 {
     LocalGroup *g = c->comm.local;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     g->bufs[c->comm.rank] = buf;
     BARRIER(c, g);
-    for (int r = 0; r < g->n; r++)
-        if (r != c->comm.rank && per)
-            HIPCHK(c, hipMemcpyAsync(buf + (uint64_t)r * per, static_cast<const double *>(g->bufs[r]) + (uint64_t)r * per, per * 8,
-                                     hipMemcpyDeviceToDevice, c->stream));
+    for (int r = 0; r < g->n; r++) {
+        uint64_t b, e;
+        comm_range(c->comm, total_cells, r, &b, &e);
+        if (r != c->comm.rank && e > b)
+            HIPCHK(c, hipMemcpyAsync(buf + b, static_cast<const double *>(g->bufs[r]) + b, (e - b) * 8, hipMemcpyDeviceToDevice, c->stream));
+    }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     BARRIER(c, g);  // nobody overwrites a slice another shard still copies
     return (int)CELLECTOR_OK;
@@ -233,12 +243,43 @@ int comm_allreduce_sum_u32(cellector_ctx *c, uint32_t *buf, uint64_t count)
     return (int)CELLECTOR_OK;
 }
 
-int comm_allgather_slices(cellector_ctx *c, double *buf, uint64_t per)
+int comm_allgather_cells(cellector_ctx *c, double *buf, uint64_t total_cells)
 {
     if (!comm_active(c->comm)) return (int)CELLECTOR_OK;
-    if (c->comm.local) return local_allgather(c, buf, per);
+    if (c->comm.local) return local_allgather(c, buf, total_cells);
     if (!c->comm.nccl) return (int)ctx_fail(c, CELLECTOR_ECOMM, "sharded ctx without a communicator");
-    // in place: the send buffer is this rank's slot of the receive buffer
-    NCCLCHK(c, g_rccl.AllGather(buf + (uint64_t)c->comm.rank * per, buf, (size_t)per, ncclDouble, (ncclComm_t)c->comm.nccl, c->stream));
+    if (!c->comm.has_bounds) {
+        // equal slots: one in-place all-gather (the send buffer is this rank's slot of the receive buffer)
+        const uint64_t per = comm_cells_per_rank(total_cells, c->comm.n);
+        NCCLCHK(c, g_rccl.AllGather(buf + (uint64_t)c->comm.rank * per, buf, (size_t)per, ncclDouble, (ncclComm_t)c->comm.nccl, c->stream));
+        return (int)CELLECTOR_OK;
+    }
+    // ranges of different length (nnz-balanced partition): every rank broadcasts its slice in place, as ONE group
+    NCCLCHK(c, g_rccl.GroupStart());
+    for (int r = 0; r < c->comm.n; r++) {
+        uint64_t b, e;
+        comm_range(c->comm, total_cells, r, &b, &e);
+        if (e > b) NCCLCHK(c, g_rccl.Broadcast(buf + b, buf + b, (size_t)(e - b), ncclDouble, r, (ncclComm_t)c->comm.nccl, c->stream));
+    }
+    NCCLCHK(c, g_rccl.GroupEnd());
     return (int)CELLECTOR_OK;
+}
+
+void comm_balanced_bounds(const uint32_t *entries_per_cell, uint64_t total_cells, int n, uint64_t *bounds)
+{
+    uint64_t total = 0;
+    for (uint64_t i = 0; i < total_cells; i++) total += entries_per_cell[i];
+    // (big ranges: whole 1024-cell blocks per shard — the rounding moves at most 512 of >= 64k cells; small ones: any cell)
+    const uint64_t align = total_cells / (uint64_t)n >= 65536 ? 1024 : 1;
+    bounds[0] = 0;
+    uint64_t run = 0, cell = 0;
+    for (int k = 1; k < n; k++) {
+        // first cell index at which the running sum reaches k / n of the entries
+        const uint64_t want = (uint64_t)(((__uint128_t)total * (uint64_t)k) / (uint64_t)n);
+        while (cell < total_cells && run + entries_per_cell[cell] <= want) run += entries_per_cell[cell++];
+        uint64_t cut = cell;
+        if (align > 1) cut = std::min(total_cells, (cut + align / 2) / align * align);
+        bounds[k] = std::max(cut, bounds[k - 1]);
+    }
+    bounds[n] = total_cells;
 }

@@ -295,6 +295,7 @@ cellector_status ingest_stage_host_coo(cellector_ctx *c, uint64_t nnz, const uin
 cellector_status ingest_pass1(cellector_ctx *c);
 cellector_status ingest_split_coo(cellector_ctx *src, uint64_t cb, uint64_t ce, uint64_t *keep, uint32_t **o_locus, uint32_t **o_cell,
                                   uint16_t **o_alt, uint16_t **o_ref, uint64_t *n_out);
+cellector_status ingest_cell_histogram(cellector_ctx *c, const uint32_t *d_cell, uint64_t n, uint64_t total_cells, std::vector<uint32_t> *out);
 // multi-device text ingest (cellector_ffi.cpp): stage the whole pair on one shard / hand a shard its routed entries
 cellector_status ffi_stage_mtx_all_cells(cellector_ctx *c, const char *alt_path, const char *ref_path, cellector_ctx *helper);
 cellector_status ffi_adopt_staged(cellector_ctx *c, uint64_t total_loci, uint64_t total_cells, uint32_t *locus, uint32_t *cell,
@@ -322,7 +323,7 @@ cellector_status mtx_input_open(const cellector_ctx *c, const char *alt_path, co
 void mtx_input_close(MtxInput *in);
 // split ingest of a multi-device ctx (kernels_parse.hip): every shard tokenises a range of windows of both files
 struct MtxSplit;
-MtxSplit *mtx_split_new(int n_shards, LocalGroup *thread_barrier);
+MtxSplit *mtx_split_new(int n_shards, LocalGroup *thread_barrier, bool balance /*cut the cells by entries, not by count*/);
 void mtx_split_delete(MtxSplit *s);
 bool mtx_input_windowed(const MtxInput *in, int64_t parse_window_opt);
 cellector_status ingest_stage_mtx_split(cellector_ctx *c, MtxInput *in, MtxSplit *s, int rank, uint64_t parse_window, uint32_t **o_locus,

@@ -355,6 +355,29 @@ __global__ __launch_bounds__(256) void k_coo_take_range(uint64_t n, const uint32
 }
 // src holds the staged COO of ALL cells (cell index global).  Writes the entries of cells [cb, ce) — cell index made local,
 // order kept — into four new arrays on src's device; `keep` is caller scratch of n + 1 words.
+// entries per (global) cell of a staged piece, on the host: what the nnz-balancing partition of a multi-device ingest is cut from
+__global__ __launch_bounds__(256) void k_cell_hist(uint64_t n, const uint32_t *__restrict__ cell, uint64_t total_cells, uint32_t *__restrict__ hist)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n && cell[i] < total_cells) atomicAdd(&hist[cell[i]], 1u);
+}
+cellector_status ingest_cell_histogram(cellector_ctx *c, const uint32_t *d_cell, uint64_t n, uint64_t total_cells, std::vector<uint32_t> *out)
+{
+    uint32_t *d_hist = nullptr;
+    out->assign(total_cells, 0u);
+    if (!total_cells) return CELLECTOR_OK;
+    CHK(dev_alloc(c, &d_hist, total_cells));
+    hipError_t e = hipMemsetAsync(d_hist, 0, total_cells * sizeof(uint32_t), c->stream);
+    if (e == hipSuccess && n)
+        hipLaunchKernelGGL(k_cell_hist, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, n, d_cell, total_cells, d_hist);
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(out->data(), d_hist, total_cells * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    dev_free(d_hist);
+    if (e != hipSuccess) return ctx_fail(c, CELLECTOR_EDEVICE, "cell histogram: %s", hipGetErrorString(e));
+    return CELLECTOR_OK;
+}
+
 cellector_status ingest_split_coo(cellector_ctx *src, uint64_t cb, uint64_t ce, uint64_t *keep, uint32_t **o_locus, uint32_t **o_cell,
                                   uint16_t **o_alt, uint16_t **o_ref, uint64_t *n_out)
 {

@@ -719,11 +719,13 @@ struct MtxSplit {
     uint32_t *pl[CELLECTOR_MAX_SHARDS][CELLECTOR_MAX_SHARDS] = {}, *pc[CELLECTOR_MAX_SHARDS][CELLECTOR_MAX_SHARDS] = {};
     uint16_t *pa[CELLECTOR_MAX_SHARDS][CELLECTOR_MAX_SHARDS] = {}, *pr[CELLECTOR_MAX_SHARDS][CELLECTOR_MAX_SHARDS] = {};
     uint64_t cnt[CELLECTOR_MAX_SHARDS][CELLECTOR_MAX_SHARDS] = {};
+    bool balance = false;                             // cut the cells so that every shard gets about the same number of entries
+    std::vector<uint32_t> hist[CELLECTOR_MAX_SHARDS];  // ... from every parser's entries per cell
 };
-MtxSplit *mtx_split_new(int n, LocalGroup *bar)
+MtxSplit *mtx_split_new(int n, LocalGroup *bar, bool balance)
 {
     MtxSplit *S = new (std::nothrow) MtxSplit();
-    if (S) { S->n = n; S->bar = bar; }
+    if (S) { S->n = n; S->bar = bar; S->balance = balance; }
     return S;
 }
 void mtx_split_delete(MtxSplit *S) { delete S; }
@@ -907,9 +909,25 @@ cellector_status ingest_stage_mtx_split(cellector_ctx *c, MtxInput *in, MtxSplit
         // (ingest_split_coo reads the staged COO of a ctx: lend it the arrays for the calls; this ctx has staged nothing yet)
         c->coo_locus = l1 + lo; c->coo_cell = c1 + lo; c->coo_alt = alt16; c->coo_ref = ref16; c->coo_n = count;
         cellector_status st = dev_alloc(c, &keep, count + 1);
-        const uint64_t per = comm_cells_per_rank(TC, n);
+        if (S->balance && st == CELLECTOR_OK) {
+            // nnz-balanced ranges: every parser counts its entries per cell, all of them add the n histograms up (the same
+            // integers on every shard) and cut the cells where the running sum crosses k / n of the entries
+            st = ingest_cell_histogram(c, c->coo_cell, count, TC, &S->hist[rank]);
+            if (st != CELLECTOR_OK) { c->coo_locus = c->coo_cell = nullptr; c->coo_alt = c->coo_ref = nullptr; c->coo_n = 0; SCHK(st); }
+            if (!S->bar->barrier()) {
+                c->coo_locus = c->coo_cell = nullptr; c->coo_alt = c->coo_ref = nullptr; c->coo_n = 0;
+                cleanup();
+                return ctx_fail(c, CELLECTOR_ECOMM, "another shard of this ctx failed during the ingest");
+            }
+            std::vector<uint32_t> epc(TC, 0u);
+            for (int k = 0; k < n; k++)
+                for (uint64_t i = 0; i < TC; i++) epc[i] += S->hist[k][i];
+            comm_balanced_bounds(epc.data(), TC, n, c->comm.bounds);
+            c->comm.has_bounds = true;
+        }
         for (int d = 0; d < n && st == CELLECTOR_OK; d++) {
-            const uint64_t cb = std::min<uint64_t>(TC, (uint64_t)d * per), ce = std::min<uint64_t>(TC, cb + per);
+            uint64_t cb, ce;
+            comm_range(c->comm, TC, d, &cb, &ce);
             st = ingest_split_coo(c, cb, ce, keep, &S->pl[rank][d], &S->pc[rank][d], &S->pa[rank][d], &S->pr[rank][d], &S->cnt[rank][d]);
         }
         c->coo_locus = c->coo_cell = nullptr; c->coo_alt = c->coo_ref = nullptr; c->coo_n = 0;

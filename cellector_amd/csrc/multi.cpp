@@ -28,6 +28,8 @@ struct MultiCtx {
     int pending = 0;
     bool stop = false;
     std::vector<cellector_status> result;
+    bool balance = true;         // option "balance": the text / COO ingest cuts the cells by entries (comm_balanced_bounds), not by count
+    bool user_partition = false;  // cellector_set_partition was called: the ingest keeps those ranges
     bool comm_aborted = false;  // (under mu) a shard failed in RCCL mode: the communicators are gone, the ctx takes no more sharded work
 };
 
@@ -177,6 +179,10 @@ int multi_n_shards(const cellector_ctx *root) { return (int)root->multi->shards.
 cellector_status multi_set_option(cellector_ctx *root, const char *key, int64_t v)
 {
     if (!strcmp(key, "norm_zero")) return CELLECTOR_OK;  // (the exchange is internal)
+    if (!strcmp(key, "balance")) {
+        root->multi->balance = v != 0;
+        return CELLECTOR_OK;
+    }
     for (cellector_ctx *s : root->multi->shards) {
         const cellector_status st = cellector_set_option(s, key, v);
         if (st != CELLECTOR_OK) {
@@ -187,8 +193,38 @@ cellector_status multi_set_option(cellector_ctx *root, const char *key, int64_t 
     return CELLECTOR_OK;
 }
 
+cellector_status multi_set_partition(cellector_ctx *root, const uint64_t *bounds, int n_bounds)
+{
+    MultiCtx *m = root->multi;
+    for (cellector_ctx *s : m->shards) {
+        const cellector_status st = cellector_set_partition(s, bounds, n_bounds);
+        if (st != CELLECTOR_OK) {
+            root->err = s->err;
+            return st;
+        }
+    }
+    m->user_partition = bounds != nullptr && n_bounds != 0;
+    return CELLECTOR_OK;
+}
+
+// the ranges of the ingest that follows: the caller's (cellector_set_partition), or cut from the entries per cell so that every
+// shard gets about the same number of entries ("balanced by nnz, not by cell count"), or — option balance = 0, and
+// the synthetic generator, whose cells are alike — equal counts
+static void set_ranges(MultiCtx *m, const uint32_t *entries_per_cell, uint64_t total_cells)
+{
+    if (m->user_partition) return;
+    const int n = (int)m->shards.size();
+    uint64_t bounds[CELLECTOR_MAX_SHARDS + 1];
+    const bool bal = m->balance && entries_per_cell && n > 1;
+    if (bal) comm_balanced_bounds(entries_per_cell, total_cells, n, bounds);
+    for (cellector_ctx *s : m->shards) {
+        s->comm.has_bounds = bal;
+        if (bal) memcpy(s->comm.bounds, bounds, sizeof(uint64_t) * (size_t)(n + 1));
+    }
+}
+
 // ---- ingest ------------------------------------------------------------------------------------------------------------------
-// (every shard sets its own canonical cell range in begin_ingest: a shard with a communicator ignores cellector_set_shard)
+// (every shard takes its cell range from its communicator in begin_ingest: a shard with one ignores cellector_set_shard)
 // The text pair is read, uploaded and tokenised ONCE — the alt file on shard 0's device, the ref file on shard 1's at the same
 // time (the two are independent byte streams until they are zipped line by line); its entries are then cut by owning cell range
 // (file order kept) and every piece goes to its shard's device (peer copy over xGMI; a plain device copy between logical
@@ -199,7 +235,10 @@ cellector_status multi_ingest_mtx(cellector_ctx *root, const char *alt_path, con
 {
     MultiCtx *m = root->multi;
     if (getenv("CELLECTOR_MULTI_PARSE_EACH"))  // (A/B: every shard parses the pair itself)
+    {
+        set_ranges(m, nullptr, 0);  // (no entry counts before the parse: equal ranges, or the caller's)
         return run_all(root, [=](cellector_ctx *s, int) { return cellector_ingest_mtx(s, alt_path, ref_path); });
+    }
     cellector_ctx *s0 = m->shards[0];
     // ---- split ingest: every GPU tokenises 1/n of both files' bytes and the entries are routed to their owners
     // (kernels_parse.hip, ingest_stage_mtx_split).  Taken when the shards sit on at least three different devices (with two,
@@ -224,7 +263,9 @@ cellector_status multi_ingest_mtx(cellector_ctx *root, const char *alt_path, con
                 const int n = (int)m->shards.size();
                 LocalGroup bar;
                 bar.n = n;
-                MtxSplit *S = mtx_split_new(n, &bar);
+                if (!m->user_partition)
+                    for (cellector_ctx *s : m->shards) s->comm.has_bounds = false;  // (the split ingest sets them, or equal ranges)
+                MtxSplit *S = mtx_split_new(n, &bar, m->balance && !m->user_partition && n > 1);
                 if (!S) { mtx_input_close(in); return ctx_fail(root, CELLECTOR_ENOMEM, "out of host memory"); }
                 const uint64_t window = s0->parse_window_opt > 0 ? (uint64_t)s0->parse_window_opt : 0;
                 st = run_all(root, [=](cellector_ctx *s, int rank) {
@@ -274,10 +315,18 @@ cellector_status multi_ingest_mtx(cellector_ctx *root, const char *alt_path, con
     uint64_t *keep = nullptr;
     st = dev_alloc(&all, &keep, all.coo_n + 1);
     const int n = (int)m->shards.size();
-    const uint64_t per = comm_cells_per_rank(TC, n);
+    if (st == CELLECTOR_OK && m->balance && !m->user_partition && n > 1) {  // the ranges: cut by entries per cell
+        std::vector<uint32_t> epc;
+        st = ingest_cell_histogram(&all, all.coo_cell, all.coo_n, TC, &epc);
+        if (st == CELLECTOR_OK) set_ranges(m, epc.data(), TC);
+        else root->err = all.err;
+    } else if (st == CELLECTOR_OK) {
+        set_ranges(m, nullptr, TC);
+    }
     for (int r = 0; r < n && st == CELLECTOR_OK; r++) {
         cellector_ctx *s = m->shards[(size_t)r];
-        const uint64_t cb = std::min(TC, (uint64_t)r * per), ce = std::min(TC, cb + per);
+        uint64_t cb, ce;
+        comm_range(s->comm, TC, r, &cb, &ce);
         uint32_t *pl = nullptr, *pc = nullptr;
         uint16_t *pa = nullptr, *pr = nullptr;
         uint64_t cnt = 0;
@@ -316,11 +365,21 @@ cellector_status multi_ingest_mtx(cellector_ctx *root, const char *alt_path, con
 cellector_status multi_ingest_coo(cellector_ctx *root, uint64_t total_loci, uint64_t total_cells, uint64_t nnz, const uint32_t *locus0,
                                   const uint32_t *cell0, const uint32_t *alt, const uint32_t *ref)
 {
+    MultiCtx *m = root->multi;
+    if (m->balance && !m->user_partition && m->shards.size() > 1 && cell0) {
+        std::vector<uint32_t> epc(total_cells, 0u);
+        for (uint64_t i = 0; i < nnz; i++)
+            if (cell0[i] < total_cells) epc[cell0[i]]++;
+        set_ranges(m, epc.data(), total_cells);
+    } else {
+        set_ranges(m, nullptr, total_cells);
+    }
     return run_all(root, [=](cellector_ctx *s, int) { return cellector_ingest_coo(s, total_loci, total_cells, nnz, locus0, cell0, alt, ref); });
 }
 cellector_status multi_ingest_synthetic(cellector_ctx *root, uint64_t total_loci, uint64_t total_cells, double density, uint64_t seed,
                                         double minority_fraction, double doublet_fraction)
 {
+    set_ranges(root->multi, nullptr, total_cells);  // (the generator's cells are alike: equal ranges)
     return run_all(root, [=](cellector_ctx *s, int) {
         return cellector_ingest_synthetic(s, total_loci, total_cells, density, seed, minority_fraction, doublet_fraction);
     });

@@ -7,6 +7,7 @@ void multi_destroy(cellector_ctx *root);
 int multi_n_shards(const cellector_ctx *root);
 cellector_ctx *multi_shard0(const cellector_ctx *root);  // per-locus state is replicated: shard 0 answers for all
 cellector_status multi_set_option(cellector_ctx *root, const char *key, int64_t v);
+cellector_status multi_set_partition(cellector_ctx *root, const uint64_t *bounds, int n_bounds);
 cellector_status multi_ingest_mtx(cellector_ctx *root, const char *alt_path, const char *ref_path);
 cellector_status multi_ingest_coo(cellector_ctx *root, uint64_t total_loci, uint64_t total_cells, uint64_t nnz, const uint32_t *locus0,
                                   const uint32_t *cell0, const uint32_t *alt, const uint32_t *ref);

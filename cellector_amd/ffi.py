@@ -30,6 +30,8 @@ SIGNATURES = {
     "cellector_set_stream": (_i, [_vp, _vp]),
     "cellector_set_option": (_i, [_vp, _cp, C.c_int64]),
     "cellector_set_shard": (_i, [_vp, _u64, _u64]),
+    "cellector_set_partition": (_i, [_vp, _vp, _i]),
+    "cellector_partition": (_i, [_vp, _vp, C.POINTER(_i)]),
     "cellector_ingest_mtx": (_i, [_vp, _cp, _cp]),
     "cellector_ingest_coo": (_i, [_vp, _u64, _u64, _u64, _vp, _vp, _vp, _vp]),
     "cellector_ingest_synthetic": (_i, [_vp, _u64, _u64, _d, _u64, _d, _d]),
@@ -171,6 +173,22 @@ class Cellector:
 
     def set_shard(self, cell_begin, cell_end):
         self._ck(self._lib.cellector_set_shard(self.h, int(cell_begin), int(cell_end)))
+
+    def set_partition(self, bounds):
+        """cell ranges of the ranks of a ctx with a communicator: n_ranks + 1 boundaries (None: back to the default)"""
+        if bounds is None:
+            self._ck(self._lib.cellector_set_partition(self.h, None, 0))
+            return
+        b = np.ascontiguousarray(bounds, dtype=np.uint64)
+        self._ck(self._lib.cellector_set_partition(self.h, _p(b), len(b)))
+
+    def partition(self):
+        """the cell ranges in use: array of n_ranks + 1 boundaries"""
+        n = C.c_int(0)
+        self._ck(self._lib.cellector_partition(self.h, None, C.byref(n)))
+        out = np.zeros(n.value + 1, np.uint64)
+        self._ck(self._lib.cellector_partition(self.h, _p(out), C.byref(n)))
+        return out
 
     # ---- ingest
     def ingest_mtx(self, alt_path, ref_path):

@@ -103,12 +103,24 @@ cellector_status cellector_set_stream(cellector_ctx *ctx, void *hip_stream);
  * "sharded_select" (1: a ctx with a communicator — cellector_create_multi, cellector_comm_init_rank — finds the
  * median / quartiles by a radix select over the shards' own keys, exchanging digit histograms: six all-reduces of 48 KB per
  * iteration; 0: every shard's normalised LLs are all-gathered and every shard selects over all of them; default -1: the
- * histograms for runs of 4 Mi cells and more on three or more ranks, else the gather; same bits either way). */
+ * histograms for runs of 4 Mi cells and more on three or more ranks, else the gather; same bits either way),
+ * "balance" (multi-device ctx, default 1: see cellector_set_partition), "ref_arith" (engine 1: every entry with the
+ * reference's own ln_gamma arithmetic, stats.rs:41-53, instead of the exact product form), "t2" / "t2_waves" (engine 2:
+ * the entries with totals 5..8 through per-(locus, pair) tables, default on unless the matrix has deep coverage). */
 cellector_status cellector_set_option(cellector_ctx *ctx, const char *key, int64_t value);
 
 /* ---- sharding (before ingest) --------------------------------------------------------------- */
 /* This ctx owns global cells [cell_begin, cell_end).  Default: all cells. */
 cellector_status cellector_set_shard(cellector_ctx *ctx, uint64_t cell_begin, uint64_t cell_end);
+/* A ctx with a communicator (cellector_create_multi, cellector_comm_init_rank) shards the cells itself: rank r owns
+ * [bounds[r], bounds[r+1]).  Default: n equal contiguous ranges — except that the text / COO ingest of a multi-device ctx
+ * cuts the ranges so that every shard holds about the same number of ENTRIES (option "balance", default 1): the reference's
+ * per-cell lists (load_data.rs:151-174) differ in length by orders of magnitude on real data, and the slowest shard sets
+ * the iteration.  cellector_set_partition gives the ranges explicitly (n_ranks + 1 non-decreasing boundaries from 0 to
+ * total_cells, the same array on every rank, before the ingest; NULL / 0 = back to the default); cellector_partition
+ * reads the ranges in use back (bounds_out may be NULL to ask for the number of ranks only). */
+cellector_status cellector_set_partition(cellector_ctx *ctx, const uint64_t *bounds, int n_bounds);
+cellector_status cellector_partition(const cellector_ctx *ctx, uint64_t *bounds_out /*[n_ranks + 1]*/, int *n_ranks);
 
 /* ---- ingest: replaces load_cell_data (load_data.rs:134-181) + get_loci_used (:254-280) ------- */
 /* Phase 1 — stage this shard's entries on the device and count, per locus, cells with ref>0 /

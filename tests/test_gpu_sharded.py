@@ -116,6 +116,100 @@ def test_multi_device_ctx_equals_single_ctx_and_oracle(devices, oracle_lib, hip_
     single.close()
 
 
+def _skewed_coo(L, N, seed):
+    """10 % of the cells (the first ones: the worst case for equal ranges) carry 50 % of the entries"""
+    rng = np.random.default_rng(seed)
+    dens = np.where(np.arange(N) < N // 10, 0.18, 0.02)
+    p, q = rng.uniform(0.05, 0.95, L), rng.uniform(0.05, 0.95, L)
+    minority = rng.random(N) < 0.08
+    lo, ce, al, re = [], [], [], []
+    for l in range(L):
+        cells = np.nonzero(rng.random(N) < dens)[0].astype(np.uint32)
+        tot = rng.geometric(0.7, len(cells)).astype(np.uint32)
+        a = rng.binomial(tot, np.where(minority[cells], q[l], p[l])).astype(np.uint32)
+        lo.append(np.full(len(cells), l, np.uint32)); ce.append(cells); al.append(a); re.append(tot - a)
+    return tuple(np.concatenate(x) for x in (lo, ce, al, re))
+
+
+def test_nnz_balanced_partition_on_a_skewed_matrix(oracle_lib, hip_lib_path, tmp_path):
+    """contiguous cell ranges "balanced by nnz, not by cell count".  The ingest of a multi-device ctx cuts the
+    ranges from the entries per cell — COO, routed text and split text ingest alike: per-shard entry counts within 5 % of
+    each other on a matrix whose first tenth of the cells holds half of the entries (equal counts: 2.6x between shards) —
+    and the run is the single-device run (labels, thresholds) whatever the ranges; explicit ranges (cellector_set_partition)
+    and option balance = 0 give what they say."""
+    from cellector_amd import Cellector, ffi, synth
+    import test_gpu_parity as T
+    L, N, n = 900, 6000, 4
+    coo = _skewed_coo(L, N, seed=12)
+    epc = np.bincount(coo[1], minlength=N)
+    assert 0.45 < epc[: N // 10].sum() / epc.sum() < 0.55
+    a_path, r_path = synth.write_mtx_pair(str(tmp_path), L, N, *coo)
+    single = Cellector(0)
+    single.load_coo(L, N, *coo)
+    runs = single.run(5.0, 30)
+    want = (single.excluded(), [(s.threshold, s.n_excluded) for s in runs], single.posteriors())
+
+    def shard_nnz(m):
+        b = m.partition()
+        assert len(b) == n + 1 and b[0] == 0 and b[-1] == N and np.all(np.diff(b.astype(np.int64)) >= 0)
+        cs = np.concatenate(([0], np.cumsum(m.entries_per_cell())))
+        return b, np.diff(cs[b.astype(np.int64)])
+
+    def same_run(m):
+        got = m.run(5.0, 30)
+        assert np.array_equal(m.excluded(), want[0])
+        assert [s.n_excluded for s in got] == [x[1] for x in want[1]]
+        np.testing.assert_allclose([s.threshold for s in got], [x[0] for x in want[1]], rtol=1e-12, atol=0)
+        p = m.posteriors()
+        np.testing.assert_allclose(p["posterior"], want[2]["posterior"], rtol=0, atol=1e-9)
+
+    for source in ("coo", "mtx", "mtx-split"):
+        m = Cellector(devices=[0] * n)
+        if source == "mtx-split":
+            os.environ["CELLECTOR_MULTI_SPLIT"] = "1"
+            m.set_option("parse_window", 4096)
+        try:
+            m.load_coo(L, N, *coo) if source == "coo" else m.load_mtx(a_path, r_path)
+        finally:
+            os.environ.pop("CELLECTOR_MULTI_SPLIT", None)
+        b, nz = shard_nnz(m)
+        assert nz.sum() == single.dims().nnz_used
+        assert nz.max() <= 1.05 * nz.min(), (source, b, nz)
+        assert b[1] < N // 8  # (the heavy cells: the first range is short)
+        o = oracle_lib.Oracle.from_coo(L, N, *coo)
+        T._check_matrix(m, o)
+        o.close()
+        same_run(m)
+        m.close()
+    # equal counts on request: the first shard then holds most of the heavy cells
+    m = Cellector(devices=[0] * n)
+    m.set_option("balance", 0)
+    m.load_coo(L, N, *coo)
+    b, nz = shard_nnz(m)
+    assert np.array_equal(b, [0, 1500, 3000, 4500, 6000]) and nz.max() > 2 * nz.min()
+    same_run(m)
+    m.close()
+    # explicit ranges, an empty one among them
+    m = Cellector(devices=[0] * n)
+    m.set_partition([0, 100, 100, 4000, N])
+    m.load_mtx(a_path, r_path)
+    b, nz = shard_nnz(m)
+    assert np.array_equal(b, [0, 100, 100, 4000, N]) and nz[1] == 0
+    same_run(m)
+    with pytest.raises(ffi.CellectorError):
+        m.set_partition([0, 1, 2, 3, N])  # (after the ingest)
+    m.close()
+    m = Cellector(devices=[0] * n)
+    for bad in ([0, 10, 5, 20, N], [1, 2, 3, 4, N], [0, 1, N]):
+        with pytest.raises(ffi.CellectorError):
+            m.set_partition(bad)
+    m.set_partition([0, 10, 20, 30, N - 1])  # does not cover the matrix: refused at the ingest
+    with pytest.raises(ffi.CellectorError):
+        m.load_coo(L, N, *coo)
+    m.close()
+    single.close()
+
+
 def test_split_text_ingest_every_shard_parses_a_byte_range(hip_lib_path, tmp_path):
     """From three devices on, every GPU of a multi-device ctx tokenises 1/n of BOTH files' bytes (window ranges), the shards
     line the files up by global line number, zip, validate and route every entry to the shard that owns its cell
