@@ -72,6 +72,7 @@ def roofline(args, kernel, launch_ms, units, b_alg, achieved, traffic, traffic_s
                       " = rate of reference-equivalent work, NOT an HBM utilisation (it can exceed 1: the kernel reads the same"
                       " entries from a 16-bit tiled layout of ~2.7 B each, see hbm_frac_measured / hbm_frac_layout and bound)",
            "algorithmic_bytes_per_launch": int(b_alg), "launch_ms": launch_ms, "entries_per_launch": int(units),
+           "launch_ms_is": "mean of HIP event pairs recorded on the launch stream around every fourth launch inside the timed region",
            "traffic": traffic,
            "traffic_is": ("HBM bytes per launch from rocprofv3 PMC passes of this command, committed as " + str(traffic_src)
                           + " (not measured inside this run)") if traffic else None,
@@ -241,7 +242,9 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    g.set_option("timing", 2)  # events around the dominant kernel only (every event pair idles the queue a few us)
+    # HIP events around the dominant kernel only, every fourth launch of the timed region (an event pair idles the queue ~10 us:
+    # 2 % of an iteration when recorded around every launch)
+    g.set_option("timing", 3)
     g.reset_timing()
     fence()
     t0 = time.perf_counter()

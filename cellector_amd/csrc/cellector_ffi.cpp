@@ -30,8 +30,12 @@ cellector_status ctx_fail(const cellector_ctx *c, cellector_status s, const char
 void timer_begin(cellector_ctx *c, int which)
 {
     if (!c->timing) return;
-    // an event pair costs a few microseconds of idle queue: level 2 keeps only the pair the roofline figure needs
-    if (c->timing == 2 && which != (c->engine == 2 ? CELLECTOR_K_TILE_LL : CELLECTOR_K_CELL_LL)) return;
+    // an event pair costs a few microseconds of idle queue (2 % of an iteration at 10^6 cells x 200k loci): level 2 keeps only the
+    // pair the roofline figure needs, level 3 records that pair around every fourth launch only
+    KernelTimer &t = c->timers[which];
+    t.open = false;
+    if (c->timing >= 2 && which != (c->engine == 2 ? CELLECTOR_K_TILE_LL : CELLECTOR_K_CELL_LL)) return;
+    if (c->timing == 3 && (t.calls++ & 3u) != 0) return;
     hipEvent_t a = nullptr, b = nullptr;
     if (c->ev_pool.size() >= 2) {
         a = c->ev_pool.back(); c->ev_pool.pop_back();
@@ -39,16 +43,16 @@ void timer_begin(cellector_ctx *c, int which)
     } else if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) {
         return;
     }
-    c->timers[which].start.push_back(a);
-    c->timers[which].stop.push_back(b);
+    t.start.push_back(a);
+    t.stop.push_back(b);
+    t.open = true;
     (void)hipEventRecord(a, c->stream);
 }
 void timer_end(cellector_ctx *c, int which)
 {
-    if (!c->timing) return;
-    if (c->timing == 2 && which != (c->engine == 2 ? CELLECTOR_K_TILE_LL : CELLECTOR_K_CELL_LL)) return;
     KernelTimer &t = c->timers[which];
-    if (t.stop.empty()) return;
+    if (!t.open || t.stop.empty()) return;  // (timer_begin recorded nothing for this launch)
+    t.open = false;
     (void)hipEventRecord(t.stop.back(), c->stream);
 }
 void timer_collect(cellector_ctx *c)
@@ -339,7 +343,8 @@ cellector_status cellector_set_option(cellector_ctx *c, const char *key, int64_t
         c->ref_arith = v != 0;
     }
     else if (!strcmp(key, "timing")) {
-        c->timing = v < 0 ? 0 : (v > 2 ? 2 : (int)v);
+        c->timing = v < 0 ? 0 : (v > 3 ? 3 : (int)v);
+        for (KernelTimer &t : c->timers) t.calls = 0;
         if (c->timing && hipSetDevice(c->device) == hipSuccess)  // events ready before the timed loop starts
             while (c->ev_pool.size() < 64) {
                 hipEvent_t e;

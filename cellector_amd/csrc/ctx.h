@@ -41,6 +41,8 @@ struct KernelTimer {
     std::vector<hipEvent_t> start, stop;  // pending pairs
     double total_ms = 0.0;
     uint64_t launches = 0;
+    uint64_t calls = 0;  // launches seen since the timing level was set (level 3 samples every fourth)
+    bool open = false;   // timer_begin recorded a start event for the launch in progress
 };
 
 struct MultiCtx;  // multi.cpp: the shards and worker threads of a ctx made by cellector_create_multi
@@ -70,7 +72,7 @@ struct cellector_ctx {
     // number of ranks (use_sharded_select)
     int sharded_select = -1;
     bool norm_zero = true;  // option: clear the other shards' slices of NORM before the cell pass (needed by a sum exchange)
-    int timing = 0;  // 0 off, 1 every timed region, 2 only the dominant kernel of the engine
+    int timing = 0;  // 0 off, 1 every timed region, 2 only the dominant kernel of the engine, 3 ... around every fourth launch
     bool keep_coo = true;
     double near_rel = CELLECTOR_NEAR_TIE_REL;  // near-tie band of this matrix, relative to max(1, |threshold|) (cellector_ingest_finish)
     int synth_continue_pct = 30;  // option synth_continue_pct: the synthetic generator's n = 1 + Geometric(1 - pct/100)

@@ -2130,7 +2130,8 @@ static void launch_overflow_cell(cellector_ctx *c, hipStream_t st, const double2
         do {                                                                                                               \
             hipLaunchKernelGGL(k_t2_tables<E>, dim3(gp + gs), dim3(256), 0, st, c->t2_np, c->t2_plist, c->t2_ns, c->t2_slist, gp, ab, c->lf, \
                                c->tab2);                                                                                   \
-            hipLaunchKernelGGL(k_t2_cell<E>, dim3(cg), dim3(64), lds_req, st, c->nloc, c->ovf_ell_ptr, c->ovf_ell, c->tab2, o_ll, o_ell); \
+            if (abl != 2) hipLaunchKernelGGL(k_t2_cell<E>, dim3(cg), dim3(64), lds_req, st, c->nloc, c->ovf_ell_ptr, c->ovf_ell, c->tab2, o_ll, o_ell); \
+            if (abl == 3) break; \
             if (need_e)                                                                                                    \
                 hipLaunchKernelGGL(k_ovf_tables_e, dim3(eg), dim3(256), 0, st, c->L, ab, c->ovf_nmask, c->ovf_tab, c->ovf_etab); \
             if (deep)                                                                                                      \
@@ -2146,6 +2147,8 @@ static void launch_overflow_cell(cellector_ctx *c, hipStream_t st, const double2
                                    c->ovf_tier_row[1], c->ovf_tier_val, c->ovf_tier_val + c->ovf_n_tier[1], o_ll, o_ell);  \
             }                                                                                                              \
         } while (0)
+        static const int abl = getenv("CELLECTOR_ABL_SIDE") ? atoi(getenv("CELLECTOR_ABL_SIDE")) : 0;  // TEMP ablation
+        if (abl == 1) return;  // no side kernels at all (wrong results)
         if (expected) T2_CELL(true); else T2_CELL(false);
 #undef T2_CELL
         return;
@@ -2408,8 +2411,10 @@ cellector_status tiled_locus_pass(cellector_ctx *c)
         hipLaunchKernelGGL(k_minority_ranges, dim3(R * c->lr_sub), dim3(LR_THREADS), 0, c->stream, c->locus_mode, c->nloc, c->L, R,
                            c->lr_sub, c->mroff_cap, c->d_counters + DC_N_MIN, c->mroff, c->mbeg, c->c4r, c->hist_min);
     }
-    if (c->t2 && c->nloc)  // the excluded cells' tier-2 entries per (locus, pair)
-        hipLaunchKernelGGL(k_t2_minority, dim3(gcap(c->nloc, 256 / LF_LANES, 1024)), dim3(256), 0, c->stream, c->d_counters + DC_N_MIN,
+    // the excluded cells' tier-2 entries per (locus, pair).  (On the side stream it does NOT run beside k_minority_ranges, whose
+    // sixteen 128-register waves per CU leave no room: it started when that kernel ended, two event gaps later.)
+    if (c->t2 && c->nloc)
+        hipLaunchKernelGGL(k_t2_minority, dim3(gcap(c->nloc / LM_DEN + 1, 256 / LF_LANES, 8192)), dim3(256), 0, c->stream, c->d_counters + DC_N_MIN,
                            c->minlist, c->ovf_ptr, c->ovf_ent, c->cnt2);
     if (c->ovf_locus_pending) {  // the overflow entries' log-pmfs of this iteration (side stream)
         HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join2, 0));

@@ -74,7 +74,8 @@ cellector_status cellector_set_stream(cellector_ctx *ctx, void *hip_stream);
 /* Options: "compute_expected" (default 1: also accumulate expected_log_beta_binomial_pmf,
  * stats.rs:8-33, into expected_ll like the reference; 0 = skip that diagnostic column),
  * "timing" (default 0; 1: record HIP events around every timed group of kernels; 2: only around
- * the engine's dominant kernel — each event pair idles the queue for a few microseconds),
+ * the engine's dominant kernel — each event pair idles the queue for a few microseconds; 3: ... around every
+ * fourth launch of it only),
  * "keep_coo" (default 1: keep the staged all-loci COO for cellector_final_allele_tallies),
  * "engine" (default 2: table-driven passes over the tiled 16-bit layout; 1: CSR/CSC kernels that
  * evaluate every entry's log-pmf — same results within rounding, kept for A/B checks; choose it before the
