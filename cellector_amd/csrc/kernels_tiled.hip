@@ -656,8 +656,7 @@ __global__ __launch_bounds__(256) void k_ovf_cell_direct(
 // 64-byte record per locus in the EM pass.  The per-lane sums are added by a fixed-shape butterfly (deterministic).
 // (Measured and dropped: one launch per locus range whose records fit an L2 — 9.3 -> 11-14 ms: the kernel is bound by its
 // arithmetic, not by the gathers.)
-// REST_ONLY (a tier-2 shard): the entries of tier 2 are k_t2_cell's; this kernel skips them and ADDS to that kernel's sums.
-template <bool EXPECTED, bool REST_ONLY>
+template <bool EXPECTED>
 __global__ __launch_bounds__(256) void k_ovf_cell_wide(uint64_t n_rows, const uint64_t *__restrict__ ovf_ptr,
                                                        const uint64_t *__restrict__ ovf_ent, const double2 *__restrict__ ab,
                                                        const double *__restrict__ lf, const double *__restrict__ etab,
@@ -682,7 +681,7 @@ __global__ __launch_bounds__(256) void k_ovf_cell_wide(uint64_t n_rows, const ui
             else if (n > (uint32_t)OV_FAST_N && n <= (uint32_t)OV_NE) ev = otab[(uint64_t)l * OV_ROW + OV_EOFF + (n - 4)];
         }
         // masked locus: no PMFData (main.rs:556); 0/0 entry: exactly zero (Q14); totals above OV_NE: the generic list
-        if (!(p.x >= 0.0) || n == 0 || n > (uint32_t)OV_NE || (REST_ONLY && t2_total(n))) continue;
+        if (!(p.x >= 0.0) || n == 0 || n > (uint32_t)OV_NE) continue;
         double lp;
         if (p.x + p.y < 1e17) {
             double num = 1.0, den = 1.0, fa = p.x, fb = p.y, fab = p.x + p.y;
@@ -704,8 +703,8 @@ __global__ __launch_bounds__(256) void k_ovf_cell_wide(uint64_t n_rows, const ui
     s = group16_sum(s);
     if (EXPECTED) e = group16_sum(e);
     if (in && j == 0) {
-        o_ll[row] = REST_ONLY ? o_ll[row] + s : s;
-        if (EXPECTED) o_ell[row] = REST_ONLY ? o_ell[row] + e : e;
+        o_ll[row] = s;
+        if (EXPECTED) o_ell[row] = e;
     }
 }
 
@@ -1959,7 +1958,10 @@ cellector_status tiled_build(cellector_ctx *c)
     // deep coverage: more than 3 % of the entries outside the tables (0.8 % with vartrix-like totals 1 + Geometric(0.7),
     // 13 % with 1 + Geometric(0.4)) — the side-stream arrangement built for "a few entries per row" no longer hides them
     c->ovf_deep = c->ovf_deep_opt >= 0 ? c->ovf_deep_opt != 0 : (c->ovf_n * 100 > c->nnz * 3);
-    c->t2 = c->ovf_n != 0 && L != 0 && L < (1ull << 27) /* the pair list's keys */ && (c->t2_opt >= 0 ? c->t2_opt != 0 : !c->ovf_deep);
+    // tier 2 (k_t2_tables): on by default.  A deep matrix takes it on the LOCUS side only (counts instead of 1300 per-entry
+    // evaluations per locus: locus pass 1.6 -> 1.0 ms at 10^6 cells x 200k loci deep); its cell side stays with the arithmetic
+    // kernel — 2.3e8 lookups of a line each out of a 77 MB table cost more than evaluating the entries (measured: 9.8 vs 6.1 ms).
+    c->t2 = c->ovf_n != 0 && L != 0 && L < (1ull << 27) /* the pair list's keys */ && (c->t2_opt >= 0 ? c->t2_opt != 0 : true);
     CHK(dev_alloc(c, &c->ovf_sum, 3 * 2 * nloc));
     CHK(dev_alloc(c, &c->ovf_tab, L * OV_ROW));
     CHK(dev_alloc(c, &c->ovc_locus, c->ovf_n));
@@ -2062,7 +2064,7 @@ cellector_status tiled_build(cellector_ctx *c)
     // which totals the per-entry tables (k_ovf_tables, k_ovf_tables_e) must cover at every locus: those of the entries that
     // take these paths
     if (L && c->ovf_n) {
-        if (c->t2)
+        if (c->t2 && !c->ovf_deep)  // (a deep matrix' cell side evaluates every overflow entry: its tables cover all totals)
             hipLaunchKernelGGL(k_ovf_nmask, dim3(gcap(L, 4)), dim3(256), 0, c->stream, L, c->ovx_ptr, c->ovx_ent, c->ovf_nmask);
         else
             hipLaunchKernelGGL(k_ovf_nmask, dim3(gcap(L, 4)), dim3(256), 0, c->stream, L, c->ovc_ptr, c->ovc_ent, c->ovf_nmask);
@@ -2117,15 +2119,15 @@ static void launch_overflow_cell(cellector_ctx *c, hipStream_t st, const double2
     double *o_ll = c->ovf_sum + (uint64_t)set * 2 * c->nloc, *o_ell = o_ll + c->nloc;
     const unsigned g = gcap(c->nloc, 256, 0x7fffffffu), eg = gcap(c->L * 16, 256, 0x7fffffffu);
     const bool deep = c->ovf_deep;  // the overflow share is large: full form, never throttled, no tier-0 list
-    if (c->t2) {
+    if (c->t2 && !deep) {
         // tier 2: the pairs' table of this pass, then the rows' lookups (writes the sums); the other totals ADD to them
         const unsigned gp = gcap(c->t2_np, 256, 0x7fffffffu), gs = expected ? gcap(c->t2_ns, 256, 0x7fffffffu) : 0u;
         // (side_lds > 0: a request for dynamic LDS the lookup kernel does not use, to limit its blocks per CU in A/B runs)
         const size_t lds_req = c->side_lds > 0 ? (size_t)c->side_lds : 0;
         // waves of the lookup kernel: all groups at once when it has the machine to itself, option t2_waves (default 512) beside the tile kernel
         const uint64_t n_grp = (c->nloc + 63) / 64;
-        const unsigned cg = (unsigned)std::min<uint64_t>(n_grp ? n_grp : 1, st == c->side && !deep ? (uint64_t)c->t2_waves : 0x7fffffffull);
-        const bool need_e = expected && (deep || c->ovf_n_tier[0]);  // E(9..17) of the tier-0 entries
+        const unsigned cg = (unsigned)std::min<uint64_t>(n_grp ? n_grp : 1, st == c->side ? (uint64_t)c->t2_waves : 0x7fffffffull);
+        const bool need_e = expected && c->ovf_n_tier[0];  // E(9..17) of the tier-0 entries
 #define T2_CELL(E)                                                                                                         \
         do {                                                                                                               \
             hipLaunchKernelGGL(k_t2_tables<E>, dim3(gp + gs), dim3(256), 0, st, c->t2_np, c->t2_plist, c->t2_ns, c->t2_slist, gp, ab, c->lf, \
@@ -2134,10 +2136,7 @@ static void launch_overflow_cell(cellector_ctx *c, hipStream_t st, const double2
             if (abl == 3) break; \
             if (need_e)                                                                                                    \
                 hipLaunchKernelGGL(k_ovf_tables_e, dim3(eg), dim3(256), 0, st, c->L, ab, c->ovf_nmask, c->ovf_tab, c->ovf_etab); \
-            if (deep)                                                                                                      \
-                hipLaunchKernelGGL((k_ovf_cell_wide<E, true>), dim3(gcap(c->nloc * LF_LANES, 256, 0x7fffffffu)), dim3(256), 0, st, c->nloc, \
-                                   c->ovf_ptr, c->ovf_ent, ab, c->lf, c->ovf_etab, c->ovf_tab, o_ll, o_ell);               \
-            else if (c->ovf_n_tier[0])                                                                                     \
+            if (c->ovf_n_tier[0])                                                                                          \
                 hipLaunchKernelGGL((k_ovf_cell_listed<E, false>), dim3(gcap(c->ovf_n_tier[0], 256, 0x7fffffffu)), dim3(256), 0, st, \
                                    c->ovf_n_tier[0], c->ovf_tier_row[0], c->ovf_tier_ent[0], ab, c->lf, c->ovf_tab, o_ll, o_ell); \
             if (c->ovf_n_tier[1]) {                                                                                        \
@@ -2160,7 +2159,7 @@ static void launch_overflow_cell(cellector_ctx *c, hipStream_t st, const double2
         // kernel and disturbs it less (cfg4: 2.83 -> 2.78 ms per iteration); a small shard's tile kernel is too short for that.
         const size_t lds_req = deep ? 0 : c->side_lds >= 0 ? (size_t)c->side_lds : (st == c->side && c->nloc >= (1ull << 19) ? 5000 : 0);
         if (deep && c->ovf_deep_wide)
-            hipLaunchKernelGGL((k_ovf_cell_wide<true, false>), dim3(gcap(c->nloc * LF_LANES, 256, 0x7fffffffu)), dim3(256), 0, st, c->nloc, c->ovf_ptr,
+            hipLaunchKernelGGL(k_ovf_cell_wide<true>, dim3(gcap(c->nloc * LF_LANES, 256, 0x7fffffffu)), dim3(256), 0, st, c->nloc, c->ovf_ptr,
                                c->ovf_ent, ab, c->lf, c->ovf_etab, c->ovf_tab, o_ll, o_ell);
         else if (deep)
             hipLaunchKernelGGL((k_ovf_cell_direct<true, false, true>), dim3(g), dim3(256), 0, st, c->nloc, c->ovf_ell_ptr, c->ovf_ell, ab,
@@ -2182,7 +2181,7 @@ static void launch_overflow_cell(cellector_ctx *c, hipStream_t st, const double2
         }
     } else {
         if (deep && c->ovf_deep_wide)
-            hipLaunchKernelGGL((k_ovf_cell_wide<false, false>), dim3(gcap(c->nloc * LF_LANES, 256, 0x7fffffffu)), dim3(256), 0, st, c->nloc, c->ovf_ptr,
+            hipLaunchKernelGGL(k_ovf_cell_wide<false>, dim3(gcap(c->nloc * LF_LANES, 256, 0x7fffffffu)), dim3(256), 0, st, c->nloc, c->ovf_ptr,
                                c->ovf_ent, ab, c->lf, c->ovf_etab, c->ovf_tab, o_ll, o_ell);
         else if (deep)
             hipLaunchKernelGGL((k_ovf_cell_direct<false, false, true>), dim3(g), dim3(256), 0, st, c->nloc, c->ovf_ell_ptr, c->ovf_ell, ab, c->lf,
@@ -2210,6 +2209,9 @@ static void launch_overflow_locus_values(cellector_ctx *c, hipStream_t st, const
                                c->lf, c->ovx_lp);
         return;
     }
+    if (c->t2)  // deep: the pairs' log-pmfs for the locus finalize's counts (the cell side does not use the table)
+        hipLaunchKernelGGL(k_t2_tables<false>, dim3(gcap(c->t2_np, 256, 0x7fffffffu)), dim3(256), 0, st, c->t2_np, c->t2_plist, c->t2_ns,
+                           c->t2_slist, gcap(c->t2_np, 256, 0x7fffffffu), ab, c->lf, c->tab2);
     hipLaunchKernelGGL(k_ovf_tables, dim3(gcap(c->L * 3, 256, 0x7fffffffu)), dim3(256), 0, st, c->L, ab, c->ovf_nmask, c->ovf_tab);
     if (!c->ovf_deep)  // shallow coverage: the values are stored here, beside the tile kernel, and the finalize reads them
         hipLaunchKernelGGL(k_ovf_values, dim3(gcap(c->ovf_n, 256, 0x7fffffffu)), dim3(256), 0, st, c->ovf_n, c->ovc_locus, c->ovc_ent, ab,
