@@ -1739,6 +1739,141 @@ __global__ __launch_bounds__(T_BC) void k_tile_build(uint64_t nloc, uint32_t nj,
     for (; k < K; k++) dst[1 + k] = T_NULL;
 }
 
+// The same tiles, built the way the memory system likes (used whenever the per-(cell, chunk) offsets table exists):
+//   * a PERSISTENT workgroup takes whole cell blocks and walks a block's tiles chunk by chunk: a thread's reads of its row move
+//     forward through one cache line after the other (a grid of one workgroup per tile spread the chunks of a block over the
+//     XCDs, and every tile fetched its 1024 row segments afresh: 2.5x the bytes);
+//   * it reads the 2-byte compact by-cell entries (c4r: locus mod 4096 | code << 12, code 15 = not a table entry) instead of the
+//     8-byte packed ones — the chunk is narrower than 4096 loci, so the slot inside it follows from the low 12 bits;
+//   * the slices are assembled in LDS and leave as whole 16-byte stores (rows written two bytes at a time straight to global
+//     memory cost 65x their bytes in partial-line traffic: 0.35 TB for 5.3 GB of tiles at 10^6 cells x 200k loci).
+// Same layout, bit for bit, as k_tile_build.
+#define TB_STAGE (40 * 1024)  // u16 of a tile staged in LDS (80 KB); a bigger tile is written directly (rows of hundreds of entries)
+__device__ __constant__ uint8_t T_NM1_OF[16] = {0, 0, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 3, 0, 0};  // alt+ref-1 of a code
+template <bool FILL>
+__global__ __launch_bounds__(T_BC) void k_tile_build2(uint64_t nloc, uint32_t nb, uint32_t nj, const uint64_t *__restrict__ csr_ptr,
+                                                      const uint16_t *__restrict__ c4r, const uint32_t *__restrict__ toff /*[row][nj + 1]*/,
+                                                      uint64_t *__restrict__ tile_elems /*count pass: out; fill: tile_ptr*/,
+                                                      uint16_t *__restrict__ tiles, uint16_t *__restrict__ thdr)
+{
+    static_assert(T_BLU < LR_LOCI, "a chunk's loci are told apart by their low 12 bits");
+    __shared__ uint32_t s_cnt[T_BC / 64][TB_BINS];
+    __shared__ uint32_t s_base[TB_BINS];
+    __shared__ uint32_t s_kmax[T_BC / 64];
+    __shared__ uint32_t s_sbase[T_BC / 64 + 1];
+    __shared__ __attribute__((aligned(16))) uint16_t s_tile[FILL ? TB_STAGE : 8];
+    const uint32_t cl = threadIdx.x, lane = cl & 63, wv = cl >> 6;
+    for (uint32_t b = blockIdx.x; b < nb; b += gridDim.x) {
+        const uint64_t row = (uint64_t)b * T_BC + cl;
+        const bool have = row < nloc;
+        const uint64_t beg = have ? csr_ptr[row] : 0;
+        const uint32_t *orow = toff + (have ? row : 0) * ((uint64_t)nj + 1);
+        uint32_t o_lo = have ? orow[0] : 0u, o_hi = have ? orow[1] : 0u;
+        for (uint32_t j = 0; j < nj; j++) {
+            const uint64_t t = (uint64_t)b * nj + j;
+            for (uint32_t i = cl; i < (T_BC / 64) * TB_BINS; i += T_BC) (&s_cnt[0][0])[i] = 0;
+            if (cl < T_BC / 64) s_kmax[cl] = 0;
+            const uint32_t o_next = have ? orow[min(j + 2u, nj)] : 0u;  // (the next chunk's end, requested a step ahead)
+            const uint64_t lo = beg + o_lo, hi = beg + o_hi;
+            // the segment's first TB_SEG entries with independent loads (one memory latency instead of one per entry); longer
+            // segments finish in loops
+            constexpr uint32_t TB_SEG = 16;
+            uint32_t seg[TB_SEG];
+            if (FILL) {
+#pragma unroll
+                for (uint32_t u = 0; u < TB_SEG; u++) seg[u] = lo + u < hi ? (uint32_t)c4r[lo + u] : 0xffffu;  // (all ones: code 15)
+            }
+            // The sort key and the row length are the segment's length INCLUDING its few overflow entries (0.8 %): the size pass then
+            // reads the offsets table only, and a row that holds one gets a padding entry in its place — sums unchanged to the bit
+            // (a row's entries stay in locus order, a padding entry adds an exact zero), 0.3 % more tile bytes.
+            const uint32_t len = o_hi - o_lo;
+            __syncthreads();
+            // stable counting sort by bin = min(len, TB_BINS-1): rank inside (wave, bin) from ballots
+            const uint32_t bin = min(len, (uint32_t)TB_BINS - 1u);
+            uint32_t within = 0;
+            {
+                unsigned long long todo = ~0ull;
+                while (todo) {
+                    const int src = __ffsll((long long)todo) - 1;
+                    const uint32_t v = (uint32_t)__shfl((int)bin, src, 64);
+                    const unsigned long long m = __ballot(bin == v);
+                    if (bin == v) within = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                    if ((int)lane == src) s_cnt[wv][v] = (uint32_t)__popcll(m);
+                    todo &= ~m;
+                }
+            }
+            __syncthreads();
+            if (cl < TB_BINS) {
+                uint32_t tot = 0;
+                for (int w = 0; w < T_BC / 64; w++) tot += s_cnt[w][cl];
+                uint32_t inc = tot;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const uint32_t o = __shfl_up(inc, off, 64);
+                    if ((int)cl >= off) inc += o;
+                }
+                s_base[cl] = inc - tot;
+            }
+            __syncthreads();
+            uint32_t rank = s_base[bin] + within;
+            for (uint32_t w = 0; w < wv; w++) rank += s_cnt[w][bin];
+            const uint32_t dw = rank >> 6, dl = rank & 63;
+            atomicMax(&s_kmax[dw], len);
+            __syncthreads();
+            if (cl == 0) {
+                uint32_t acc = 0;
+                for (int w = 0; w < T_BC / 64; w++) {
+                    s_sbase[w] = acc;
+                    acc += 64u * ((s_kmax[w] | 1u) + 1u);
+                }
+                s_sbase[T_BC / 64] = acc;
+            }
+            __syncthreads();
+            const uint32_t total = s_sbase[T_BC / 64];  // a multiple of 128 u16
+            if (!FILL) {
+                if (cl == 0) tile_elems[t] = (uint64_t)total;
+            } else {
+                const uint64_t tbase = tile_elems[t];
+                if (cl < T_BC / 64) {
+                    uint32_t *hd = reinterpret_cast<uint32_t *>(thdr + t * T_HDR) + 4 * cl;
+                    const uint64_t first = tbase + s_sbase[cl];
+                    hd[0] = (uint32_t)first;
+                    hd[1] = (uint32_t)(first >> 32);
+                    hd[2] = s_kmax[cl] | 1u;
+                    hd[3] = 0;
+                }
+                const uint32_t K = s_kmax[dw] | 1u;
+                const bool staged = total <= (uint32_t)TB_STAGE;  // (uniform)
+                uint16_t *dst = (staged ? s_tile : tiles + tbase) + s_sbase[dw] + dl * (K + 1u);
+                dst[0] = (uint16_t)cl;
+                uint32_t k = 0;
+                const uint32_t cbase = (j * (uint32_t)T_BLU) & (LR_LOCI - 1u);
+#define TB_PUT(E)                                                                                                       \
+                do {                                                                                                   \
+                    const uint32_t e__ = (E), code__ = e__ >> 12;                                                      \
+                    if (code__ < (uint32_t)T_NCODE)                                                                    \
+                        dst[1 + k++] = (uint16_t)(((uint32_t)T_NM1_OF[code__] << 14) |                                 \
+                                                  ((((e__ & (LR_LOCI - 1u)) - cbase) & (LR_LOCI - 1u)) << 4) | code__); \
+                } while (0)
+#pragma unroll
+                for (uint32_t u = 0; u < TB_SEG; u++) TB_PUT(seg[u]);
+                for (uint64_t i = lo + TB_SEG; i < hi; i++) TB_PUT((uint32_t)c4r[i]);
+#undef TB_PUT
+                for (; k < K; k++) dst[1 + k] = T_NULL;
+                if (staged) {
+                    __syncthreads();
+                    uint4 *out = reinterpret_cast<uint4 *>(tiles + tbase);  // (tile starts are multiples of 128 u16)
+                    const uint4 *in = reinterpret_cast<const uint4 *>(s_tile);
+                    for (uint32_t i = cl; i < total / 8u; i += T_BC) out[i] = in[i];
+                }
+            }
+            __syncthreads();  // (the sort's arrays and the staged tile are reused by the next chunk)
+            o_lo = o_hi;
+            o_hi = o_next;
+        }
+    }
+}
+
 // wave per row/column: count entries that are NOT regular (FILL = false) or copy them in order (FILL = true);
 // REST: only those outside tier 2 as well (totals 0 and above 8)
 template <bool FILL, bool REST = false>
@@ -1882,11 +2017,23 @@ cellector_status tiled_build(cellector_ctx *c)
                            c->csr_ent, toff);
     else
         toff = nullptr;  // (no room for the table: the builder searches)
+    // the compact by-cell entries (also the minority-driven locus pass' input): with the offsets table the builder reads these
+    CHK(dev_alloc(c, &c->c4r, c->nnz));
+    if (c->nnz)
+        hipLaunchKernelGGL(k_cell_compact, dim3(gcap(c->nnz, 256, 0x7fffffffu)), dim3(256), 0, c->stream, c->nnz, c->csr_ent, c->c4r);
+    int ncu_b = 256;
+    (void)hipDeviceGetAttribute(&ncu_b, hipDeviceAttributeMultiprocessorCount, c->device);
+    const unsigned bgrid = (unsigned)std::min<uint64_t>(c->t_nb, (uint64_t)ncu_b * 8);  // (one block per CU at a time: LDS)
     const uint64_t maxg = 1ull << 30;
-    for (uint64_t t0 = 0; t0 < nt; t0 += maxg) {
-        const uint64_t g = nt - t0 < maxg ? nt - t0 : maxg;
-        hipLaunchKernelGGL(k_tile_build<false>, dim3((unsigned)g), dim3(T_BC), 0, c->stream, nloc, c->t_nj, t0, c->csr_ptr,
-                           c->csr_ent, c->tile_ptr, (uint16_t *)nullptr, (uint16_t *)nullptr, toff);
+    if (toff) {
+        hipLaunchKernelGGL(k_tile_build2<false>, dim3(bgrid), dim3(T_BC), 0, c->stream, nloc, c->t_nb, c->t_nj, c->csr_ptr, c->c4r, toff,
+                           c->tile_ptr, (uint16_t *)nullptr, (uint16_t *)nullptr);
+    } else {
+        for (uint64_t t0 = 0; t0 < nt; t0 += maxg) {
+            const uint64_t g = nt - t0 < maxg ? nt - t0 : maxg;
+            hipLaunchKernelGGL(k_tile_build<false>, dim3((unsigned)g), dim3(T_BC), 0, c->stream, nloc, c->t_nj, t0, c->csr_ptr,
+                               c->csr_ent, c->tile_ptr, (uint16_t *)nullptr, (uint16_t *)nullptr, toff);
+        }
     }
     HIPCHK(c, hipGetLastError());
     uint64_t elems = 0;
@@ -1894,10 +2041,15 @@ cellector_status tiled_build(cellector_ctx *c)
     CHK(dev_alloc(c, &c->tiles, elems + 64));  // tail pad: the 16-byte load of the last row runs past its end
     CHK(dev_alloc(c, &c->thdr, nt * T_HDR));
     c->t_elems = elems;
-    for (uint64_t t0 = 0; t0 < nt; t0 += maxg) {
-        const uint64_t g = nt - t0 < maxg ? nt - t0 : maxg;
-        hipLaunchKernelGGL(k_tile_build<true>, dim3((unsigned)g), dim3(T_BC), 0, c->stream, nloc, c->t_nj, t0, c->csr_ptr,
-                           c->csr_ent, c->tile_ptr, c->tiles, c->thdr, toff);
+    if (toff) {
+        hipLaunchKernelGGL(k_tile_build2<true>, dim3(bgrid), dim3(T_BC), 0, c->stream, nloc, c->t_nb, c->t_nj, c->csr_ptr, c->c4r, toff,
+                           c->tile_ptr, c->tiles, c->thdr);
+    } else {
+        for (uint64_t t0 = 0; t0 < nt; t0 += maxg) {
+            const uint64_t g = nt - t0 < maxg ? nt - t0 : maxg;
+            hipLaunchKernelGGL(k_tile_build<true>, dim3((unsigned)g), dim3(T_BC), 0, c->stream, nloc, c->t_nj, t0, c->csr_ptr,
+                               c->csr_ent, c->tile_ptr, c->tiles, c->thdr, toff);
+        }
     }
     if (toff) {
         HIPCHK(c, hipStreamSynchronize(c->stream));  // (the block goes back to the allocation cache: no kernel may still read it)
@@ -2095,10 +2247,6 @@ cellector_status tiled_build(cellector_ctx *c)
         c->lr_sub = sub;
         CHK(dev_alloc(c, &c->hist_min, (uint64_t)sub * L * 16));
         CHK(dev_alloc(c, &c->roff, nloc * (R + 1)));
-        CHK(dev_alloc(c, &c->c4r, c->nnz));
-        if (c->nnz)
-            hipLaunchKernelGGL(k_cell_compact, dim3(gcap(c->nnz, 256, 0x7fffffffu)), dim3(256), 0, c->stream, c->nnz, c->csr_ent,
-                               c->c4r);
         if (nloc)
             hipLaunchKernelGGL(k_range_offsets, dim3(gcap(nloc, 4)), dim3(256), 0, c->stream, nloc, R, (uint32_t)LR_LOCI, c->csr_ptr, c->csr_ent,
                                c->roff);
