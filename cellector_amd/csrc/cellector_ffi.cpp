@@ -48,6 +48,27 @@ void timer_begin(cellector_ctx *c, int which)
     t.open = true;
     (void)hipEventRecord(a, c->stream);
 }
+// the event pair of a launch whose start and stop ride on the kernel's own dispatch (hipExtLaunchKernelGGL): no barrier packets
+// in the queue, i.e. none of the idle time a recorded pair costs.  False: this launch is not timed.
+bool timer_take(cellector_ctx *c, int which, hipEvent_t *a_out, hipEvent_t *b_out)
+{
+    if (!c->timing) return false;
+    KernelTimer &t = c->timers[which];
+    if (c->timing >= 2 && which != (c->engine == 2 ? CELLECTOR_K_TILE_LL : CELLECTOR_K_CELL_LL)) return false;
+    if (c->timing == 3 && (t.calls++ & 3u) != 0) return false;
+    hipEvent_t a = nullptr, b = nullptr;
+    if (c->ev_pool.size() >= 2) {
+        a = c->ev_pool.back(); c->ev_pool.pop_back();
+        b = c->ev_pool.back(); c->ev_pool.pop_back();
+    } else if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) {
+        return false;
+    }
+    // (kept apart from the recorded pairs' open / close bookkeeping: both events belong to one dispatch)
+    t.start.insert(t.start.begin(), a);
+    t.stop.insert(t.stop.begin(), b);
+    *a_out = a; *b_out = b;
+    return true;
+}
 void timer_end(cellector_ctx *c, int which)
 {
     KernelTimer &t = c->timers[which];
@@ -59,18 +80,22 @@ void timer_collect(cellector_ctx *c)
 {
     for (int k = 0; k < CELLECTOR_K_COUNT; k++) {
         KernelTimer &t = c->timers[k];
-        for (size_t i = 0; i < t.start.size(); i++) {
+        // (a pair whose stop event is still to be recorded — the first half of a cell pass queued ahead by em_finish — stays)
+        const size_t n_done = t.start.size() - (t.open && !t.start.empty() ? 1 : 0);
+        for (size_t i = 0; i < n_done; i++) {
             float ms = 0.f;
             if (hipEventSynchronize(t.stop[i]) == hipSuccess &&
                 hipEventElapsedTime(&ms, t.start[i], t.stop[i]) == hipSuccess) {
                 t.total_ms += ms;
                 t.launches++;
+            } else {
+                (void)hipGetLastError();  // (an event that was never recorded: not this call's caller's error)
             }
             c->ev_pool.push_back(t.start[i]);
             c->ev_pool.push_back(t.stop[i]);
         }
-        t.start.clear();
-        t.stop.clear();
+        t.start.erase(t.start.begin(), t.start.begin() + (long)n_done);
+        t.stop.erase(t.stop.begin(), t.stop.begin() + (long)n_done);
     }
 }
 
@@ -95,6 +120,7 @@ static void free_matrix(cellector_ctx *c)
     // nothing built ahead for the previous matrix survives a reload: the next em_begin must form alpha/beta and the
     // tables itself (em_finish leaves tables_prebuilt set; the new matrix' table buffers are fresh allocations)
     c->tables_prebuilt = false; c->prebuilt_expected = false; c->work_zeroed = false; c->ovf_locus_pending = false;
+    c->cell_join_pending = false;
 }
 
 // the side stream gets the lowest priority the device offers: its kernels should only fill slots the main stream's
@@ -249,7 +275,8 @@ cellector_status cellector_create(cellector_ctx **out, int device_id)
               hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) == hipSuccess &&
               hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) == hipSuccess &&
               hipEventCreateWithFlags(&c->ev_join2, hipEventDisableTiming) == hipSuccess &&
-              hipEventCreateWithFlags(&c->ev_sum, hipEventDisableTiming) == hipSuccess;
+              hipEventCreateWithFlags(&c->ev_sum, hipEventDisableTiming) == hipSuccess &&
+              hipEventCreateWithFlags(&c->ev_tab, hipEventDisableTiming) == hipSuccess;
     if (!ok) {
         cellector_destroy(c);
         return CELLECTOR_EDEVICE;
@@ -318,6 +345,7 @@ void cellector_destroy(cellector_ctx *c)
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->ev_join2) (void)hipEventDestroy(c->ev_join2);
     if (c->ev_sum) (void)hipEventDestroy(c->ev_sum);
+    if (c->ev_tab) (void)hipEventDestroy(c->ev_tab);
     delete c;
     dev_cache_trim();
 }
@@ -872,7 +900,10 @@ cellector_status cellector_em_finish(cellector_ctx *c, cellector_iter_summary *o
     // the next iteration's first kernel is queued behind the summary: it runs while the host waits for the summary, wakes
     // up and decides (should the loop end here, the tables it built are simply never used)
     if (c->engine == 2 && c->tiled_ready) CHK(tiled_prebuild_tables(c));
-    HIPCHK(c, hipEventRecord(c->ev_sum, c->stream));  // (behind that kernel: an event between the two idles the queue ~6 us)
+    // the fallback of the poll below: the event that rides on the table kernel's dispatch, else one recorded behind the summary
+    hipEvent_t ev_wait = c->tab_event_valid ? c->ev_tab : c->ev_sum;
+    if (!c->tab_event_valid) HIPCHK(c, hipEventRecord(c->ev_sum, c->stream));
+
     // The iteration's only host synchronisation.  The summary kernel stores its sequence number behind the values in
     // pinned memory: polling that wakes the host a few tens of microseconds before hipEventSynchronize returns, and the
     // next iteration's tile kernel is the next thing the GPU waits for.  (The event stays the fallback: it is polled too,
@@ -887,9 +918,9 @@ cellector_status cellector_em_finish(cellector_ctx *c, cellector_iter_summary *o
             memcpy(&have, &bits, sizeof have);
             if (have == want) break;
             if ((spin & 0xfffu) == 0) {
-                if (hipEventQuery(c->ev_sum) == hipSuccess) break;
+                if (hipEventQuery(ev_wait) == hipSuccess) break;
                 if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) {
-                    HIPCHK(c, hipEventSynchronize(c->ev_sum));
+                    HIPCHK(c, hipEventSynchronize(ev_wait));
                     break;
                 }
             }

@@ -60,6 +60,8 @@ struct cellector_ctx {
     // side stream for the small overflow kernels that run next to the tile kernel (fork/join with events)
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr, ev_sum = nullptr;
+    hipEvent_t ev_tab = nullptr;   // completion of the table kernel queued ahead by em_finish, attached to its dispatch (no barrier packet)
+    bool tab_event_valid = false;  // ... and nothing the side stream depends on has been queued behind it since
     int overlap = 1;  // option "overlap": 1 = the overflow kernels run on the side stream next to the tile kernel, 0 = in front
     mutable std::string err;
 
@@ -198,6 +200,7 @@ struct cellector_ctx {
     bool tables_prebuilt = false;   // the next iteration's k_build_tables is already queued / done (em_finish)
     bool prebuilt_expected = false; // ... with this value of compute_expected
     bool work_zeroed = false;       // tile_work was reset by this iteration's k_alpha_beta
+    bool cell_join_pending = false; // the main stream still has to wait for the side stream's cell-side overflow sums (ev_join)
 
     // iteration bookkeeping
     uint64_t iteration = 0;
@@ -270,6 +273,7 @@ static inline hipError_t dev_copy_sync(hipStream_t st, void *dst, int dst_dev, c
 // ---- timing -----------------------------------------------------------------------------------
 void timer_begin(cellector_ctx *c, int which);
 void timer_end(cellector_ctx *c, int which);
+bool timer_take(cellector_ctx *c, int which, hipEvent_t *start, hipEvent_t *stop);
 void timer_collect(cellector_ctx *c);
 
 // ---- launch wrappers (kernels_*.hip) ------------------------------------------------------------

@@ -28,6 +28,8 @@
 #include <algorithm>
 #include <type_traits>
 
+#include <hip/hip_ext.h>
+
 #include "ctx.h"
 #include "device_math.h"
 
@@ -2371,6 +2373,11 @@ static bool have_overflow(const cellector_ctx *c) { return c->ovf_n != 0 && c->L
 // fork: the side stream starts after everything already queued on the main stream (alpha/beta are ready there)
 static cellector_status side_fork(cellector_ctx *c)
 {
+    if (c->tab_event_valid) {  // the table kernel is the last thing queued on the main stream and its completion has an event
+        c->tab_event_valid = false;
+        HIPCHK(c, hipStreamWaitEvent(c->side, c->ev_tab, 0));
+        return CELLECTOR_OK;
+    }
     HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
     HIPCHK(c, hipStreamWaitEvent(c->side, c->ev_fork, 0));
     return CELLECTOR_OK;
@@ -2385,8 +2392,9 @@ static cellector_status side_join(cellector_ctx *c)
 
 // the chunk tables of one pass
 static cellector_status build_tile_tables(cellector_ctx *c, const double2 *ab, int set, bool expected, bool form_ab = false,
-                                          const uint8_t *mask = nullptr)
+                                          const uint8_t *mask = nullptr, hipEvent_t done = nullptr /*rides on the dispatch*/)
 {
+    c->tab_event_valid = false;
     const uint64_t tab_elems = (uint64_t)c->t_nj * TAB_ELEMS;
     double *tab = expected ? c->tab + 3 * tab_elems : c->tab + (uint64_t)set * tab_elems;
     const unsigned tgrid = gcap((uint64_t)c->t_nj * T_BL, 64);
@@ -2400,7 +2408,15 @@ static cellector_status build_tile_tables(cellector_ctx *c, const double2 *ab, i
         src.tile_work = c->tile_work; src.n_work = 3u * T_GROUPS_MAX;
         c->work_zeroed = true;
     }
-    if (expected)
+    if (done) {  // (an event RECORDED behind the kernel is a barrier packet of its own: ~6 us of idle queue in front of the next kernel)
+        if (expected)
+            hipExtLaunchKernelGGL(k_build_tables<true>, dim3(tgrid), dim3(64 * TB_PARTS), 0, c->stream, nullptr, done, 0, c->L, c->t_nj, ab,
+                                  (const double *)c->lf, tab, src);
+        else
+            hipExtLaunchKernelGGL(k_build_tables<false>, dim3(tgrid), dim3(64 * TB_PARTS), 0, c->stream, nullptr, done, 0, c->L, c->t_nj, ab,
+                                  (const double *)c->lf, tab, src);
+        c->tab_event_valid = true;
+    } else if (expected)
         hipLaunchKernelGGL(k_build_tables<true>, dim3(tgrid), dim3(64 * TB_PARTS), 0, c->stream, c->L, c->t_nj, ab, c->lf, tab, src);
     else
         hipLaunchKernelGGL(k_build_tables<false>, dim3(tgrid), dim3(64 * TB_PARTS), 0, c->stream, c->L, c->t_nj, ab, c->lf, tab, src);
@@ -2434,24 +2450,31 @@ static cellector_status run_tile_pass(cellector_ctx *c, int set, bool expected)
     static_assert(T_GROUPS_MAX == CELLECTOR_TILE_WORK_STRIDE, "k_alpha_beta resets the counters with this stride");
     if (!(set == 0 && c->work_zeroed))  // else: reset by this iteration's k_alpha_beta
         HIPCHK(c, hipMemsetAsync(work, 0, T_GROUPS_MAX * sizeof(uint32_t), c->stream));
-    timer_begin(c, CELLECTOR_K_TILE_LL);
+    hipEvent_t t_a = nullptr, t_b = nullptr;  // the timer's events ride on the dispatch: no barrier packets around the kernel
+    const bool timed = timer_take(c, CELLECTOR_K_TILE_LL, &t_a, &t_b);
 #define LAUNCH_TILE(E, S)                                                                                                  \
-    hipLaunchKernelGGL((k_tile_ll<E, S>), grid, dim3(T_THREADS), 0, c->stream, c->t_nb, c->t_nj, c->t_cpg, c->t_groups, n_cols, \
-                       work, c->thdr, c->tiles, tab, c->t_npad, part_ll, part_ell)
+    do {                                                                                                                   \
+        if (timed)                                                                                                         \
+            hipExtLaunchKernelGGL((k_tile_ll<E, S>), grid, dim3(T_THREADS), 0, c->stream, t_a, t_b, 0, c->t_nb, c->t_nj, c->t_cpg, \
+                                  c->t_groups, n_cols, work, (const uint16_t *)c->thdr, (const uint16_t *)c->tiles,        \
+                                  (const double *)tab, c->t_npad, part_ll, part_ell);                                      \
+        else                                                                                                               \
+            hipLaunchKernelGGL((k_tile_ll<E, S>), grid, dim3(T_THREADS), 0, c->stream, c->t_nb, c->t_nj, c->t_cpg, c->t_groups, \
+                               n_cols, work, c->thdr, c->tiles, tab, c->t_npad, part_ll, part_ell);                        \
+    } while (0)
     if (expected) {
         if (sb == 4) LAUNCH_TILE(true, 4); else LAUNCH_TILE(true, 2);
     } else {
         if (sb == 4) LAUNCH_TILE(false, 4); else LAUNCH_TILE(false, 2);
     }
 #undef LAUNCH_TILE
-    timer_end(c, CELLECTOR_K_TILE_LL);
     HIPCHK(c, hipGetLastError());
     return CELLECTOR_OK;
 }
 
-cellector_status tiled_cell_pass(cellector_ctx *c, const double2 *ab, double *norm_out, bool for_em)
+// first half of the cell pass: tables, the tile kernel and the overflow kernels beside it (results in scratch arrays)
+static cellector_status cell_pass_launch(cellector_ctx *c, const double2 *ab, bool for_em)
 {
-    if (c->nloc == 0) return CELLECTOR_OK;
     timer_begin(c, CELLECTOR_K_CELL_LL);
     const bool ovf = have_overflow(c);
     // The overflow entries' cell side runs on the side stream BESIDE the tile kernel: in the few wave slots the persistent
@@ -2482,13 +2505,28 @@ cellector_status tiled_cell_pass(cellector_ctx *c, const double2 *ab, double *no
             HIPCHK(c, hipEventRecord(c->ev_join2, c->side));
             c->ovf_locus_pending = true;
         }
-        HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
+        c->cell_join_pending = true;
     } else {
         if (ovf) {
             launch_overflow_cell(c, c->stream, ab, 0, c->compute_expected);
             if (for_em) launch_overflow_locus_values(c, c->stream, ab);
         }
         CHK(run_tile_pass(c, 0, c->compute_expected));
+    }
+    return CELLECTOR_OK;
+}
+
+cellector_status tiled_cell_pass(cellector_ctx *c, const double2 *ab, double *norm_out, bool for_em)
+{
+    if (c->nloc == 0) return CELLECTOR_OK;
+    const bool ovf = have_overflow(c);
+    // (Measured and dropped: em_finish queueing this first half for the NEXT iteration right behind its table kernel, so that the
+    //  tile kernel starts without waiting for the host to read the summary and launch — no gain at 10^6 cells, none on a 125k-cell
+    //  shard: 0.50 vs 0.49 ms.  The ~15 us between the table kernel and the tile kernel are not the host's.)
+    CHK(cell_pass_launch(c, ab, for_em));
+    if (c->cell_join_pending) {  // the overflow entries' cell-side sums (side stream)
+        HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
+        c->cell_join_pending = false;
     }
     double *part_ll = c->part, *part_ell = c->part + (uint64_t)c->t_groups * c->t_npad;
     const double *o_ll = ovf ? c->ovf_sum : nullptr, *o_ell = ovf ? c->ovf_sum + c->nloc : nullptr;
@@ -2592,7 +2630,7 @@ cellector_status tiled_locus_pass(cellector_ctx *c)
 cellector_status tiled_prebuild_tables(cellector_ctx *c)
 {
     if (c->nloc == 0 || c->L == 0) return CELLECTOR_OK;
-    CHK(build_tile_tables(c, c->ab, 0, c->compute_expected, true, c->mask_next));
+    CHK(build_tile_tables(c, c->ab, 0, c->compute_expected, true, c->mask_next, c->ev_tab));
     c->tables_prebuilt = true;
     c->prebuilt_expected = c->compute_expected;
     return CELLECTOR_OK;
@@ -2615,6 +2653,10 @@ cellector_status tiled_masked_update(cellector_ctx *c)
 cellector_status tiled_posteriors(cellector_ctx *c, double mf0, double lp_min, double lp_maj, double lp_dbl)
 {
     c->tables_prebuilt = false;  // the posterior passes rebuild table set 0 and use its column counters
+    if (c->cell_join_pending) {
+        HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
+        c->cell_join_pending = false;
+    }
     c->work_zeroed = false;
     const uint64_t L = c->L;
     if (L)
