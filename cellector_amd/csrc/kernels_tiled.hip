@@ -2282,8 +2282,7 @@ static void launch_overflow_cell(cellector_ctx *c, hipStream_t st, const double2
         do {                                                                                                               \
             hipLaunchKernelGGL(k_t2_tables<E>, dim3(gp + gs), dim3(256), 0, st, c->t2_np, c->t2_plist, c->t2_ns, c->t2_slist, gp, ab, c->lf, \
                                c->tab2);                                                                                   \
-            if (abl != 2) hipLaunchKernelGGL(k_t2_cell<E>, dim3(cg), dim3(64), lds_req, st, c->nloc, c->ovf_ell_ptr, c->ovf_ell, c->tab2, o_ll, o_ell); \
-            if (abl == 3) break; \
+            hipLaunchKernelGGL(k_t2_cell<E>, dim3(cg), dim3(64), lds_req, st, c->nloc, c->ovf_ell_ptr, c->ovf_ell, c->tab2, o_ll, o_ell); \
             if (need_e)                                                                                                    \
                 hipLaunchKernelGGL(k_ovf_tables_e, dim3(eg), dim3(256), 0, st, c->L, ab, c->ovf_nmask, c->ovf_tab, c->ovf_etab); \
             if (c->ovf_n_tier[0])                                                                                          \
@@ -2296,8 +2295,6 @@ static void launch_overflow_cell(cellector_ctx *c, hipStream_t st, const double2
                                    c->ovf_tier_row[1], c->ovf_tier_val, c->ovf_tier_val + c->ovf_n_tier[1], o_ll, o_ell);  \
             }                                                                                                              \
         } while (0)
-        static const int abl = getenv("CELLECTOR_ABL_SIDE") ? atoi(getenv("CELLECTOR_ABL_SIDE")) : 0;  // TEMP ablation
-        if (abl == 1) return;  // no side kernels at all (wrong results)
         if (expected) T2_CELL(true); else T2_CELL(false);
 #undef T2_CELL
         return;
