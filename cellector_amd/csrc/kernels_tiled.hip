@@ -2253,6 +2253,14 @@ cellector_status tiled_build(cellector_ctx *c)
             hipLaunchKernelGGL(k_range_offsets, dim3(gcap(nloc, 4)), dim3(256), 0, c->stream, nloc, R, (uint32_t)LR_LOCI, c->csr_ptr, c->csr_ent,
                                c->roff);
         HIPCHK(c, hipGetLastError());
+        // the transposed offsets of the excluded cells, sized for the largest exclusion set the automatic choice hands to the
+        // minority-driven form (allocated here, not in the first iteration's locus pass: that cost the first iteration a
+        // stream synchronisation and two allocations — and a run has few iterations)
+        if (nloc && c->locus_mode != 1) {
+            c->mroff_cap = ((nloc * LM_NUM / LM_DEN + LT_CELLS) + 63) & ~63ull;
+            CHK(dev_alloc(c, &c->mroff, (uint64_t)(R + 1) * c->mroff_cap));
+            CHK(dev_alloc(c, &c->mbeg, c->mroff_cap));
+        }
     }
     HIPCHK(c, hipMemsetAsync(c->masked_cnt, 0, (nloc ? nloc : 1) * 4, c->stream));
     HIPCHK(c, hipMemsetAsync(c->flag_bits, 0, ((nloc + 31) / 32 + 1) * 4, c->stream));
