@@ -381,6 +381,7 @@ cellector_status cellector_set_option(cellector_ctx *c, const char *key, int64_t
             }
     }
     else if (!strcmp(key, "keep_coo")) c->keep_coo = v != 0;
+    else if (!strcmp(key, "bank_order")) c->bank_order = v != 0;
     else if (!strcmp(key, "synth_continue_pct")) {
         if (v < 0 || v > 90) return ctx_fail(c, CELLECTOR_EINVAL, "synth_continue_pct must be within 0..90");
         c->synth_continue_pct = (int)v;

@@ -1741,6 +1741,122 @@ __global__ __launch_bounds__(T_BC) void k_tile_build(uint64_t nloc, uint32_t nj,
     for (; k < K; k++) dst[1 + k] = T_NULL;
 }
 
+// Bank-aware order of the entries inside the rows of one slice (option "bank_order"; a wave per slice, lane = row, the slice's rows
+// in LDS).  The tile kernel's lookup step k reads, for the 32 lanes of a half-wave, the log-pmf at slot * 18 + code and the
+// expected term at slot * 18 + 14 + (n - 1): two 8-byte LDS reads per lane, served at one cycle per DISTINCT address on the busiest
+// of the 32 bank pairs.  In file order the banks are random — 3.3 cycles per step and half-wave instead of 1 — and those conflicts
+// are 42 % of the kernel's time (SQ_LDS_BANK_CONFLICT).  A row's sum does not care about the order of its entries beyond rounding,
+// so the builder picks it: step by step, every lane whose entry of this step is still open proposes the cheapest of its remaining
+// entries given the bank loads of the lanes already placed in the step; of the proposers that share a bank pair the lowest lane is
+// placed, the others propose again; after four rounds whoever is left takes its proposal.  Simulated (tools/probe/bank_sim.py):
+// 3.3 -> 2.4 cycles per step, the same as placing the lanes one after the other.  Deterministic; the order inside a row then depends
+// on the 31 rows that share its half-wave, i.e. on the shard's cell set: per-cell sums of differently sharded runs differ in the
+// last bits (as they already do between different chunk-group counts).
+#define TBO_ROUNDS 4
+__device__ __forceinline__ void tbo_banks(uint32_t e, uint32_t *a, uint32_t *b)
+{
+    const uint32_t base = ((e >> 4) & 1023u) * (uint32_t)T_LROW;
+    *a = (base + (e & 15u)) & 31u;
+    *b = (base + (uint32_t)T_NCODE + (e >> 14)) & 31u;
+}
+// Which lane of its slice a row takes (any permutation of a slice's 64 rows is a valid layout).  The tile kernel adds a row's
+// sums to its cell's accumulator in LDS with one 16-byte read and one 16-byte write per lane: address = cell * 16, served in
+// groups of 16 lanes (read: {0-3,12-15,20-27}, {4-11,16-19,28-31}, and the same + 32) resp. 8 contiguous lanes (write), one cycle
+// per distinct address on a bank quad = cell mod 16.  Rows in count order carry arbitrary cells — 2.7 addresses on the busiest
+// quad of a read group.  Here the slice's rows are ranked by (cell mod 16, lane) and dealt round-robin to the four read groups,
+// the second and fourth group shifted by half a group so that two rows of one class never share a write group either: classes of
+// up to four rows (the average) become conflict-free.  Returns the row count that now belongs to this lane.
+__device__ uint32_t tile_lane_assign(uint16_t *slice /*64 rows of Kw + 1 u16*/, uint32_t Kw, uint32_t lane, uint32_t cnt, uint32_t *scr)
+{
+#define TLA_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+    const uint32_t cls = (uint32_t)slice[lane * (Kw + 1u)] & 15u;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    uint32_t t = 0;
+#pragma unroll
+    for (uint32_t c = 0; c < 16u; c++) {
+        const unsigned long long m = __ballot(cls == c);
+        if (c < cls) t += (uint32_t)__popcll(m);
+        else if (c == cls) t += (uint32_t)__popcll(m & lt);
+    }
+    const uint32_t g = t & 3u, pp = ((t >> 2) + ((g & 1u) ? 8u : 0u)) & 15u;
+    // lane number pp of read group g & 1 (G0 = 0-3, 12-15, 20-27; G1 = 4-11, 16-19, 28-31), upper half for g >= 2
+    const uint32_t l0 = pp < 4u ? pp : (pp < 8u ? pp + 8u : pp + 12u);          // G0: 0..3 | 12..15 | 20..27
+    const uint32_t l1 = pp < 8u ? pp + 4u : (pp < 12u ? pp + 8u : pp + 16u);    // G1: 4..11 | 16..19 | 28..31
+    const uint32_t dst = ((g & 1u) ? l1 : l0) + ((g & 2u) ? 32u : 0u);
+    scr[dst] = lane;
+    scr[64 + dst] = cnt;
+    TLA_SYNC();
+    const uint32_t src = scr[lane], cnt_new = scr[64 + lane];
+    for (uint32_t k = 0; k <= Kw; k++) {  // column by column: all of a column's reads before its writes
+        const uint16_t v = slice[src * (Kw + 1u) + k];
+        TLA_SYNC();
+        slice[lane * (Kw + 1u) + k] = v;
+        TLA_SYNC();
+    }
+    return cnt_new;
+#undef TLA_SYNC
+}
+
+#define TBO_WIN 4  // candidates per lane and round: its next four remaining entries (the whole rest is no better: 2.46 vs 2.50 cycles)
+__device__ void tile_bank_order(uint16_t *row /*this lane's K entries*/, uint32_t K, uint32_t cnt /*real entries: the first cnt*/,
+                                uint32_t lane, uint32_t *scr /*[256]: this wave's bank loads and claims*/)
+{
+    const uint32_t h = lane >> 5;
+    uint32_t *ld_a = scr + h * 64, *ld_b = ld_a + 32, *win_a = scr + 128 + h * 64, *win_b = win_a + 32;
+    // (one wave: its LDS operations complete in program order; the asm statements only keep the compiler from moving them)
+#define TBO_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+    if (K <= 1u) return;  // (wave-uniform) nothing to choose
+    for (uint32_t k = 0; k + 1u < K; k++) {
+        if (__ballot(k + 1u < cnt) == 0ull) break;  // no lane has two entries left to choose from
+        scr[lane] = 0u; scr[64 + lane] = 0u;  // the step's loads
+        // this lane's candidates: its next TBO_WIN remaining entries, and their bank pairs
+        uint32_t e[TBO_WIN], ca[TBO_WIN], cb[TBO_WIN];
+#pragma unroll
+        for (uint32_t u = 0; u < (uint32_t)TBO_WIN; u++) {
+            e[u] = k + u < cnt ? (uint32_t)row[k + u] : 0xffffffffu;
+            tbo_banks(e[u], &ca[u], &cb[u]);
+        }
+        bool open = k < cnt;  // (a row out of real entries keeps its padding entry: one shared address)
+        TBO_SYNC();
+        for (uint32_t rd = 0; rd < (uint32_t)TBO_ROUNDS; rd++) {
+            if (__ballot(open) == 0ull) break;
+            scr[128 + lane] = ~0u; scr[192 + lane] = ~0u;  // the round's claims
+            uint32_t cost[TBO_WIN];
+#pragma unroll
+            for (uint32_t u = 0; u < (uint32_t)TBO_WIN; u++) cost[u] = ld_a[ca[u]] + ld_b[cb[u]];
+            uint32_t best = 0, bc = cost[0];
+#pragma unroll
+            for (uint32_t u = 1; u < (uint32_t)TBO_WIN; u++)
+                if (e[u] != 0xffffffffu && cost[u] < bc) { bc = cost[u]; best = u; }
+            uint32_t ba = ca[0], bb = cb[0];
+#pragma unroll
+            for (uint32_t u = 1; u < (uint32_t)TBO_WIN; u++)
+                if (best == u) { ba = ca[u]; bb = cb[u]; }
+            TBO_SYNC();
+            if (open) {
+                atomicMin(&win_a[ba], lane);
+                atomicMin(&win_b[bb], lane);
+            }
+            TBO_SYNC();
+            if (open && (rd == (uint32_t)TBO_ROUNDS - 1u || (win_a[ba] == lane && win_b[bb] == lane))) {
+                if (best) {  // swap the chosen entry into position k
+                    uint32_t eb = e[0];
+#pragma unroll
+                    for (uint32_t u = 1; u < (uint32_t)TBO_WIN; u++)
+                        if (best == u) eb = e[u];
+                    row[k] = (uint16_t)eb;
+                    row[k + best] = (uint16_t)e[0];
+                }
+                atomicAdd(&ld_a[ba], 1u);
+                atomicAdd(&ld_b[bb], 1u);
+                open = false;
+            }
+            TBO_SYNC();
+        }
+    }
+#undef TBO_SYNC
+}
+
 // The same tiles, built the way the memory system likes (used whenever the per-(cell, chunk) offsets table exists):
 //   * a PERSISTENT workgroup takes whole cell blocks and walks a block's tiles chunk by chunk: a thread's reads of its row move
 //     forward through one cache line after the other (a grid of one workgroup per tile spread the chunks of a block over the
@@ -1750,10 +1866,10 @@ __global__ __launch_bounds__(T_BC) void k_tile_build(uint64_t nloc, uint32_t nj,
 //   * the slices are assembled in LDS and leave as whole 16-byte stores (rows written two bytes at a time straight to global
 //     memory cost 65x their bytes in partial-line traffic: 0.35 TB for 5.3 GB of tiles at 10^6 cells x 200k loci).
 // Same layout, bit for bit, as k_tile_build.
-#define TB_STAGE (40 * 1024)  // u16 of a tile staged in LDS (80 KB); a bigger tile is written directly (rows of hundreds of entries)
+#define TB_STAGE (24 * 1024)  // u16 of a tile staged in LDS (48 KB: two workgroups per CU); a bigger tile is written directly (rows of hundreds of entries)
 __device__ __constant__ uint8_t T_NM1_OF[16] = {0, 0, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 3, 0, 0};  // alt+ref-1 of a code
-template <bool FILL>
-__global__ __launch_bounds__(T_BC) void k_tile_build2(uint64_t nloc, uint32_t nb, uint32_t nj, const uint64_t *__restrict__ csr_ptr,
+template <bool FILL, bool ORDER = false>
+__global__ __launch_bounds__(T_BC, 8) void k_tile_build2(uint64_t nloc, uint32_t nb, uint32_t nj, const uint64_t *__restrict__ csr_ptr,
                                                       const uint16_t *__restrict__ c4r, const uint32_t *__restrict__ toff /*[row][nj + 1]*/,
                                                       uint64_t *__restrict__ tile_elems /*count pass: out; fill: tile_ptr*/,
                                                       uint16_t *__restrict__ tiles, uint16_t *__restrict__ thdr)
@@ -1764,6 +1880,8 @@ __global__ __launch_bounds__(T_BC) void k_tile_build2(uint64_t nloc, uint32_t nb
     __shared__ uint32_t s_kmax[T_BC / 64];
     __shared__ uint32_t s_sbase[T_BC / 64 + 1];
     __shared__ __attribute__((aligned(16))) uint16_t s_tile[FILL ? TB_STAGE : 8];
+    __shared__ uint32_t s_scr[ORDER ? (T_BC / 64) * 256 : 1];  // bank-aware order: a wave's loads and claims
+    __shared__ uint16_t s_rcnt[ORDER ? T_BC : 1];              // ... real entries of every row of the tile, by (slice, lane)
     const uint32_t cl = threadIdx.x, lane = cl & 63, wv = cl >> 6;
     for (uint32_t b = blockIdx.x; b < nb; b += gridDim.x) {
         const uint64_t row = (uint64_t)b * T_BC + cl;
@@ -1861,9 +1979,16 @@ __global__ __launch_bounds__(T_BC) void k_tile_build2(uint64_t nloc, uint32_t nb
                 for (uint32_t u = 0; u < TB_SEG; u++) TB_PUT(seg[u]);
                 for (uint64_t i = lo + TB_SEG; i < hi; i++) TB_PUT((uint32_t)c4r[i]);
 #undef TB_PUT
+                if (ORDER) s_rcnt[rank] = (uint16_t)k;
                 for (; k < K; k++) dst[1 + k] = T_NULL;
                 if (staged) {
                     __syncthreads();
+                    if (ORDER) {  // wave wv = slice wv, lane = row
+                        const uint32_t Kw = s_kmax[wv] | 1u;
+                        const uint32_t rc = tile_lane_assign(s_tile + s_sbase[wv], Kw, lane, s_rcnt[wv * 64 + lane], s_scr + wv * 256);
+                        tile_bank_order(s_tile + s_sbase[wv] + lane * (Kw + 1u) + 1u, Kw, rc, lane, s_scr + wv * 256);
+                        __syncthreads();
+                    }
                     uint4 *out = reinterpret_cast<uint4 *>(tiles + tbase);  // (tile starts are multiples of 128 u16)
                     const uint4 *in = reinterpret_cast<const uint4 *>(s_tile);
                     for (uint32_t i = cl; i < total / 8u; i += T_BC) out[i] = in[i];
@@ -2044,8 +2169,12 @@ cellector_status tiled_build(cellector_ctx *c)
     CHK(dev_alloc(c, &c->thdr, nt * T_HDR));
     c->t_elems = elems;
     if (toff) {
-        hipLaunchKernelGGL(k_tile_build2<true>, dim3(bgrid), dim3(T_BC), 0, c->stream, nloc, c->t_nb, c->t_nj, c->csr_ptr, c->c4r, toff,
-                           c->tile_ptr, c->tiles, c->thdr);
+        if (c->bank_order)
+            hipLaunchKernelGGL((k_tile_build2<true, true>), dim3(bgrid), dim3(T_BC), 0, c->stream, nloc, c->t_nb, c->t_nj, c->csr_ptr, c->c4r,
+                               toff, c->tile_ptr, c->tiles, c->thdr);
+        else
+            hipLaunchKernelGGL((k_tile_build2<true, false>), dim3(bgrid), dim3(T_BC), 0, c->stream, nloc, c->t_nb, c->t_nj, c->csr_ptr, c->c4r,
+                               toff, c->tile_ptr, c->tiles, c->thdr);
     } else {
         for (uint64_t t0 = 0; t0 < nt; t0 += maxg) {
             const uint64_t g = nt - t0 < maxg ? nt - t0 : maxg;

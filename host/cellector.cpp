@@ -418,6 +418,7 @@ int main(int argc, char **argv)
         die(EXIT_PANIC, "cellector: no usable MI355X device (asked for " + std::to_string(devices.size()) + ", first: " +
                             std::to_string(devices[0]) + "; there is no CPU fallback)");
     if (const char *e = getenv("CELLECTOR_ENGINE")) g.ck(cellector_set_option(g.c, "engine", atoi(e)), "engine");
+    if (const char *e = getenv("CELLECTOR_BANK_ORDER")) g.ck(cellector_set_option(g.c, "bank_order", atoi(e)), "bank_order");
     g.ck(cellector_set_option(g.c, "keep_coo", params.vcf ? 1 : 0), "option");
     lap("barcodes + device init");
     g.ck(cellector_load_mtx(g.c, params.alt_mtx.c_str(), params.ref_mtx.c_str(), params.min_alt, params.min_ref), "load_cell_data");

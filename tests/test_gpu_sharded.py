@@ -44,10 +44,14 @@ def test_multi_device_ctx_equals_single_ctx_and_oracle(devices, oracle_lib, hip_
     L, N, d = 1500, 1201, 0.1   # 1201 cells: shards of unequal size, the last one ragged
     coo = synth.generate_coo(L, N, d, seed=4, minority_fraction=0.06, doublet_fraction=0.01)
     a_path, r_path = synth.write_mtx_pair(str(tmp_path), L, N, *coo)
+    # (bank_order = 0: rows in file order, the layout whose per-cell sums do not depend on the sharding — this test compares bits;
+    #  the default order is compared within rounding in test_nnz_balanced_partition_on_a_skewed_matrix)
     single = Cellector(0)
+    single.set_option("bank_order", 0)
     single.load_coo(L, N, *coo)
     for source in ("coo", "mtx"):
         m = Cellector(devices=devices)
+        m.set_option("bank_order", 0)
         # exchange point 2 both ways per shard count: digit histograms, or NORM all-gather + select over all keys
         m.set_option("sharded_select", 1 if source == "coo" else 0)
         if source == "coo":
@@ -229,6 +233,7 @@ def test_split_text_ingest_every_shard_parses_a_byte_range(hip_lib_path, tmp_pat
     ref_lines = open(r_path).read().split("\n", 3)
     open(r_path, "w").write(ref_lines[0] + "\n% a longer comment line than the alt file has, to shift every window\n" + ref_lines[2] + "\n" + ref_lines[3])
     single = Cellector(0)
+    single.set_option("bank_order", 0)  # (rows in file order: thresholds are compared bit for bit across shardings below)
     single.load_mtx(a_path, r_path, 2, 2)
     rs, es = single.csr_rows(0, N)
     it_single = [single.em_iteration(5.0) for _ in range(3)]
@@ -236,6 +241,7 @@ def test_split_text_ingest_every_shard_parses_a_byte_range(hip_lib_path, tmp_pat
     try:
         for n_shards, window in ((3, 4096), (5, 512), (7, 1 << 15), (2, 640)):
             m = Cellector(devices=[0] * n_shards)
+            m.set_option("bank_order", 0)
             m.set_option("parse_window", window)
             m.load_mtx(a_path, r_path, 2, 2)
             dm, ds = m.dims(), single.dims()
