@@ -143,11 +143,13 @@ __global__ __launch_bounds__(64 * TB_PARTS) void k_build_tables(uint64_t L, uint
 #endif
 // Workgroup barrier that waits for this wave's LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it would wait
 // for the prefetch loads in flight and make them synchronous.
-#ifndef TILE_PF4
-// 1: rows requested four steps (= one chunk) ahead when a column has four blocks, 0: two steps.  Measured at cfg4: the kernel
-// itself 1.955 -> 1.87 ms, but at 123 VGPRs (97 with two buffers) its four waves per SIMD take the whole register file, the
-// overflow kernels of the side stream find no room beside it and run behind it instead: cell pass 2.02 -> 2.26 ms.  Off.
-#define TILE_PF4 0
+#ifndef TILE_PFD
+// Prefetch distance of the tile rows in steps (a column of four blocks; two blocks: always 2) = number of row buffers.
+// 4 (a whole chunk ahead), round 2 at cfg4: the kernel itself 1.955 -> 1.87 ms, but at 123 VGPRs (97 with two buffers) its four
+// waves per SIMD take the whole register file, the overflow kernels of the side stream find no room beside it and run behind it
+// instead: cell pass 2.02 -> 2.26 ms.  3: three buffers rotating over the four steps of a chunk, the chunk loop written out three
+// times (the buffer of a step must be known at compile time).
+#define TILE_PFD 2
 #endif
 #ifndef TILE_PINNED
 #define TILE_PINNED 1
@@ -242,7 +244,8 @@ __global__ __launch_bounds__(T_THREADS, 4) void k_tile_ll(uint32_t nb, uint32_t 
 
     // PFD = prefetch distance in steps = number of pipeline buffers.  With four blocks per column every block of the chunk has
     // a buffer of its own and the rows are requested a whole chunk ahead.
-    constexpr uint32_t PFD = (T_SB == 4 && TILE_PF4) ? 4u : 2u;
+    constexpr uint32_t PFD = T_SB == 4 ? (uint32_t)TILE_PFD : 2u;
+    static_assert(PFD >= 2 && PFD <= 4, "row buffers");
     uint4 h0, h1, h2, h3;   // at the top of step t (t % PFD == 0): slice headers of steps t+PFD (h0), t+PFD+1 (h1), ...
     row_t e0, e1, e2, e3;   // at the top of step t (t % PFD == 0): rows of steps t (e0), t+1 (e1), ...
     // The table loads are the OLDEST requests when the chunk loop is entered, like on its back edge, so that the wait
@@ -252,19 +255,22 @@ __global__ __launch_bounds__(T_THREADS, 4) void k_tile_ll(uint32_t nb, uint32_t 
     __builtin_amdgcn_sched_barrier(0);
     HDR_LOAD(h0, 0);
     HDR_LOAD(h1, 1);
-    if constexpr (PFD == 4) { HDR_LOAD(h2, 2); HDR_LOAD(h3, 3); }
+    if constexpr (PFD >= 3) HDR_LOAD(h2, 2);
+    if constexpr (PFD == 4) HDR_LOAD(h3, 3);
     ROW_LOAD(e0, h0);
     ROW_LOAD(e1, h1);
-    if constexpr (PFD == 4) { ROW_LOAD(e2, h2); ROW_LOAD(e3, h3); }
+    if constexpr (PFD >= 3) ROW_LOAD(e2, h2);
+    if constexpr (PFD == 4) ROW_LOAD(e3, h3);
     HDR_LOAD(h0, PFD);
     HDR_LOAD(h1, PFD + 1);
-    if constexpr (PFD == 4) { HDR_LOAD(h2, PFD + 2); HDR_LOAD(h3, PFD + 3); }
+    if constexpr (PFD >= 3) HDR_LOAD(h2, PFD + 2);
+    if constexpr (PFD == 4) HDR_LOAD(h3, PFD + 3);
     uint32_t t = 0;
 
     // one step: block S of the current chunk, pipeline buffers E / H
     // lookup of entry KK of the row = u16 number KK + 1 = half (KK + 1) & 1 of dword (KK + 1) >> 1.  The slice's K is odd
     // and wave-uniform, so the lookups come in pairs behind one scalar branch.
-#if TILE_ABL == 1  /* ablation: no table lookups */
+#if TILE_ABL == 1 || TILE_ABL == 5  /* ablation: no table lookups */
 #define TILE_LOOKUP(V, E16) do { if constexpr (EXPECTED) V = make_double2((double)(E16), 1.0); else V = (double)(E16); } while (0)
 #elif TILE_ABL == 4  /* ablation: lookups free of bank conflicts (a lane keeps to its own bank pair; wrong values) */
 #define TILE_LOOKUP(V, E16)                                                                                      \
@@ -326,7 +332,7 @@ __global__ __launch_bounds__(T_THREADS, 4) void k_tile_ll(uint32_t nb, uint32_t 
         HDR_LOAD(H, t + 2 * PFD);                                                                                \
         /* 3. the cell's accumulator is requested first (LDS answers in order: it has landed when the sums are done), */ \
         /*    then this lane's cell of the slice: K lookups for every lane (padding entries hit the zero row) */  \
-        tab_t acc__ = s_acc[(S) * T_BC + cell__];                                                                \
+        tab_t acc__ = s_acc[(S) * T_BC + (TILE_ABL == 6 ? tid : cell__)];                                        \
         double a_ll__ = 0.0, a_el__ = 0.0;                                                                       \
         /* (written out: a loop with an early exit gets re-rolled and then selects its register at run time) */  \
         TILE_RD(v0, 0);                                                                                          \
@@ -351,39 +357,64 @@ __global__ __launch_bounds__(T_THREADS, 4) void k_tile_ll(uint32_t nb, uint32_t 
         /*    are separated by the chunk barriers).  A read and a write: two ds_add_f64 measured 15 % slower.      */ \
         if constexpr (EXPECTED) { acc__.x += a_ll__; acc__.y += a_el__; }                                        \
         else acc__ += a_ll__;                                                                                    \
-        s_acc[(S) * T_BC + cell__] = acc__;                                                                      \
+        s_acc[(S) * T_BC + (TILE_ABL == 6 ? tid : cell__)] = acc__;                                              \
         t++;                                                                                                     \
     } while (0)
 
     static_assert(T_SB == 2 || T_SB == 4, "even and odd steps use different pipeline buffers");
-    for (uint32_t j = j0; j < j1; j++) {
-        TILE_BARRIER();  // every wave is done with the previous chunk's table (and, first time, s_acc is zeroed)
-#if TILE_ABL == 3  /* ablation: table staged for the first chunk only */
-        if (j == j0)
+    // the table of chunk j into LDS between two barriers, the next chunk's table requested
+#if TILE_ABL == 3 || TILE_ABL == 5  /* ablation: table staged for the first chunk only */
+#define TILE_STAGE_IF if (j == j0)
+#define TILE_NEXT_TABLE() do { } while (0)
+#else
+#define TILE_STAGE_IF
+#define TILE_NEXT_TABLE() TABLE_PREFETCH(min(j + 1, j1 - 1))
 #endif
-        {
-            double2 *dst = reinterpret_cast<double2 *>(s_tab) + tid;
-            dst[0] = p_t0;
-            dst[T_THREADS] = p_t1;
-            dst[2 * T_THREADS] = p_t2;
-            dst[3 * T_THREADS] = p_t3;
-            dst[4 * T_THREADS] = p_t4;
-            if (tid + 5 * T_THREADS < TAB_U) dst[5 * T_THREADS] = p_t5;
+#define TILE_STAGE()                                                                                             \
+    do {                                                                                                         \
+        TILE_BARRIER(); /* every wave is done with the previous chunk's table (and, first time, s_acc is zeroed) */ \
+        TILE_STAGE_IF {                                                                                          \
+            double2 *dst = reinterpret_cast<double2 *>(s_tab) + tid;                                             \
+            dst[0] = p_t0;                                                                                       \
+            dst[T_THREADS] = p_t1;                                                                               \
+            dst[2 * T_THREADS] = p_t2;                                                                           \
+            dst[3 * T_THREADS] = p_t3;                                                                           \
+            dst[4 * T_THREADS] = p_t4;                                                                           \
+            if (tid + 5 * T_THREADS < TAB_U) dst[5 * T_THREADS] = p_t5;                                          \
+        }                                                                                                        \
+        TILE_NEXT_TABLE();                                                                                       \
+        TILE_BARRIER(); /* table visible */                                                                      \
+    } while (0)
+    if constexpr (T_SB == 4 && PFD == 3) {
+        // three row buffers over four steps per chunk: the assignment repeats every three chunks
+        for (uint32_t j = j0;;) {
+            TILE_STAGE();
+            TILE_STEP(0, e0, h0); TILE_STEP(1, e1, h1); TILE_STEP(2, e2, h2); TILE_STEP(3, e0, h0);
+            if (++j >= j1) break;
+            TILE_STAGE();
+            TILE_STEP(0, e1, h1); TILE_STEP(1, e2, h2); TILE_STEP(2, e0, h0); TILE_STEP(3, e1, h1);
+            if (++j >= j1) break;
+            TILE_STAGE();
+            TILE_STEP(0, e2, h2); TILE_STEP(1, e0, h0); TILE_STEP(2, e1, h1); TILE_STEP(3, e2, h2);
+            if (++j >= j1) break;
         }
-#if TILE_ABL != 3
-        TABLE_PREFETCH(min(j + 1, j1 - 1));
-#endif
-        TILE_BARRIER();  // table visible
-        TILE_STEP(0, e0, h0);
-        TILE_STEP(1, e1, h1);
-        if constexpr (T_SB == 4 && PFD == 4) {
-            TILE_STEP(2, e2, h2);
-            TILE_STEP(3, e3, h3);
-        } else if constexpr (T_SB == 4) {
-            TILE_STEP(2, e0, h0);
-            TILE_STEP(3, e1, h1);
+    } else {
+        for (uint32_t j = j0; j < j1; j++) {
+            TILE_STAGE();
+            TILE_STEP(0, e0, h0);
+            TILE_STEP(1, e1, h1);
+            if constexpr (T_SB == 4 && PFD == 4) {
+                TILE_STEP(2, e2, h2);
+                TILE_STEP(3, e3, h3);
+            } else if constexpr (T_SB == 4) {
+                TILE_STEP(2, e0, h0);
+                TILE_STEP(3, e1, h1);
+            }
         }
     }
+#undef TILE_STAGE
+#undef TILE_STAGE_IF
+#undef TILE_NEXT_TABLE
     TILE_BARRIER();
 #pragma unroll
     for (int s = 0; s < T_SB; s++) {
@@ -832,7 +863,11 @@ __global__ __launch_bounds__(64) void k_t2_cell(uint64_t n_rows, const uint64_t 
         for (int u = 0; u < U; u++) {
             const uint32_t r = ENT_REF(en[u]), n = ENT_ALT(en[u]) + r;
             const bool ok = en[u] != OVF_PAD && t2_total(n);
+#ifdef T2_ABL  /* ablation: every lookup falls into the first 1024 loci's rows (384 KB: L2 hits; wrong values) */
+            const uint64_t at = (uint64_t)(ENT_IDX(en[u]) & 1023u) * T2_ROW + t2_pos(ok ? n : T2_NMIN, ok ? r : 0u);
+#else
             const uint64_t at = (uint64_t)ENT_IDX(en[u]) * T2_ROW + t2_pos(ok ? n : T2_NMIN, ok ? r : 0u);
+#endif
             lp[u] = ok ? tab2[at] : 0.0;
             if (EXPECTED) ev[u] = ok ? tab2[at & ~7ull] : 0.0;
         }
