@@ -408,6 +408,12 @@ cellector_status cellector_set_option(cellector_ctx *c, const char *key, int64_t
             return ctx_fail(c, CELLECTOR_EINVAL, "t2 decides which overflow layouts the ingest builds: set it before the ingest");
         c->t2_opt = (int)v;
     }
+    else if (!strcmp(key, "t2_tiles")) {
+        if (!(v == -1 || v == 0 || v == 6 || v == 8)) return ctx_fail(c, CELLECTOR_EINVAL, "t2_tiles must be -1 (automatic), 0, 6 or 8");
+        if (c->tiled_ready && v >= 0 && c->t2_tiles != (int)v)
+            return ctx_fail(c, CELLECTOR_EINVAL, "t2_tiles decides which layouts the ingest builds: set it before the ingest");
+        c->t2_tiles_opt = (int)v;
+    }
     else if (!strcmp(key, "norm_zero")) c->norm_zero = v != 0;
     else if (!strcmp(key, "sharded_select")) c->sharded_select = v < 0 ? -1 : (v != 0);
     else if (!strcmp(key, "parse_window")) c->parse_window_opt = v < 0 ? 0 : v;

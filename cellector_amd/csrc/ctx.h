@@ -159,6 +159,18 @@ struct cellector_ctx {
     uint32_t *t2_pmask = nullptr;    // [L] bit c2: the pair occurs at the locus (static)
     uint32_t *cnt2 = nullptr;        // [L][32] ... of the cells of the new exclusion set (k_t2_minority; cleared by k_locus_finalize)
     double *tab2 = nullptr;          // [L][48] per pass: log-pmfs of the pairs that occur + expected terms, six 64-byte sectors per locus
+    // tier-2 TILES (deep coverage; kernels_tiled.hip, geo_t2): the cell side of the totals 5..t2_tiles walks a second tile set with
+    // its own chunk tables in LDS instead of evaluating those entries one by one (k_ovf_cell_wide keeps the other totals)
+    int t2_tiles_opt = -1;           // option "t2_tiles": -1 = automatic (8 on an ovf_deep matrix), 0 = off, 6 / 8 = totals 5..6 / 5..8
+    int t2_tiles = 0;                // 0, 6 or 8: in use (tiled_build)
+    uint32_t t2_nj = 0, t2_groups = 0, t2_cpg = 0;  // chunks of geo_t2::BLU loci, chunk groups, chunks per group
+    uint64_t *tile2_ptr = nullptr;   // [nb * t2_nj + 1]
+    uint16_t *tiles2 = nullptr, *thdr2 = nullptr;
+    double *tab2c = nullptr;         // [t2_nj][geo_t2::BL][geo_t2::LROW] per pass: the chunked tier-2 tables (+ tail pad)
+    double *part2 = nullptr;         // [3][2][t2_groups][npad] per-group partial sums of the tier-2 tile passes
+    uint32_t *tile_work2 = nullptr;  // [T_GROUPS_MAX] column counters of a tier-2 tile pass
+    uint64_t *ovr_ptr = nullptr, *ovr_ent = nullptr;  // by-cell CSR of the overflow entries the tier-2 tiles leave out (totals 0, above t2_tiles)
+    uint64_t ovr_n = 0;
     uint64_t *ovx_ptr = nullptr, *ovx_ent = nullptr;  // by-locus CSC of the overflow entries outside tier 2 (totals 0 and above 8)
     uint32_t *ovx_locus = nullptr;   // [ovx_n] their compact locus index
     double *ovx_lp = nullptr;        // [ovx_n] the EM pass' log-pmfs of those entries (k_ovx_values -> k_locus_finalize)

@@ -151,14 +151,34 @@ __global__ __launch_bounds__(64 * TB_PARTS) void k_build_tables(uint64_t L, uint
 // times (the buffer of a step must be known at compile time).
 #define TILE_PFD 2
 #endif
+#ifndef TILE_PFD_T2
+#define TILE_PFD_T2 2  // ... of the tier-2 tiles (deep coverage): short rows, little work per step
+#endif
 #ifndef TILE_PINNED
 #define TILE_PINNED 1
 #endif
 #define TILE_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
+// Table / entry geometry of a tile set.  geo_reg: the regular entries (totals 1..T_K): 18 doubles per locus, u16 entry =
+// n-1 << 14 | slot << 4 | code.  geo_t2<NMAX>: the tier-2 tiles of a deep-coverage matrix (totals 5..NMAX, tiled_build):
+// NMAX = 8: 30 log-pmfs + 4 expected terms per locus, 338 loci per chunk, entry = n-5 << 14 | slot << 5 | pair;
+// NMAX = 6: 13 + 2 doubles per locus, 767 loci per chunk, entry = n-5 << 14 | slot << 4 | pair.
+struct geo_reg {
+    static constexpr uint32_t LROW = T_LROW, BL = T_BL, NCODE = T_NCODE, SHIFT = 4, SMASK = 1023u, CMASK = 15u;
+    static constexpr uint32_t BLU = BL - 1, NLO = 1, NHI = T_K;  // loci per chunk (the last slot is all zeros); totals covered
+};
+template <int NMAX>
+struct geo_t2 {
+    static_assert(NMAX == 6 || NMAX == 8, "tier-2 tile geometries");
+    static constexpr uint32_t NCODE = NMAX == 8 ? 30 : 13, NE = NMAX - 4, LROW = NCODE + NE;
+    static constexpr uint32_t BL = NMAX == 8 ? 339 : 768, SHIFT = NMAX == 8 ? 5 : 4, SMASK = NMAX == 8 ? 511u : 1023u,
+                              CMASK = NMAX == 8 ? 31u : 15u;
+    static constexpr uint32_t BLU = BL - 1, NLO = 5, NHI = NMAX;
+};
+
 struct __attribute__((packed, aligned(4))) tile_u4 { uint32_t x, y, z, w; };  // 16-byte load at a 4-byte aligned address
 
-template <bool EXPECTED, int T_SB>
+template <bool EXPECTED, int T_SB, class G = geo_reg>
 __global__ __launch_bounds__(T_THREADS, 4) void k_tile_ll(uint32_t nb, uint32_t nj, uint32_t cpg, uint32_t groups,
                                                           uint32_t n_cols, uint32_t *__restrict__ work /*[groups], zeroed*/,
                                                           const uint16_t *__restrict__ thdr,
@@ -176,10 +196,11 @@ __global__ __launch_bounds__(T_THREADS, 4) void k_tile_ll(uint32_t nb, uint32_t 
     // consumed FIRST, then the next loads are issued as straight-line, unconditional instructions (indices are clamped
     // instead of guarded).
     using tab_t = typename std::conditional<EXPECTED, double2, double>::type;  // (log-pmf, expected) sums of a cell
-    constexpr uint32_t TAB_U = T_LROW * T_BL * sizeof(double) / 16;  // 16-byte units per chunk table
+    constexpr uint32_t TAB_U = G::LROW * G::BL * sizeof(double) / 16;  // 16-byte units per chunk table
     constexpr int NP = (TAB_U + T_THREADS - 1) / T_THREADS;          // units per thread (the last one partial)
     static_assert(NP == 6, "table prefetch registers are written out by hand");
-    __shared__ __attribute__((aligned(16))) double s_tab[T_LROW * T_BL];
+    __shared__ __attribute__((aligned(16))) double s_tab[G::LROW * G::BL];
+    static_assert(G::LROW * G::BL % 2 == 0, "whole 16-byte units");
     __shared__ tab_t s_acc[T_SB * T_BC];  // per-cell sums of the workgroup's blocks
     __shared__ uint32_t s_col;
     const uint32_t tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
@@ -244,7 +265,7 @@ __global__ __launch_bounds__(T_THREADS, 4) void k_tile_ll(uint32_t nb, uint32_t 
 
     // PFD = prefetch distance in steps = number of pipeline buffers.  With four blocks per column every block of the chunk has
     // a buffer of its own and the rows are requested a whole chunk ahead.
-    constexpr uint32_t PFD = T_SB == 4 ? (uint32_t)TILE_PFD : 2u;
+    constexpr uint32_t PFD = T_SB == 4 ? (uint32_t)(G::NLO == 1 ? TILE_PFD : TILE_PFD_T2) : 2u;
     static_assert(PFD >= 2 && PFD <= 4, "row buffers");
     uint4 h0, h1, h2, h3;   // at the top of step t (t % PFD == 0): slice headers of steps t+PFD (h0), t+PFD+1 (h1), ...
     row_t e0, e1, e2, e3;   // at the top of step t (t % PFD == 0): rows of steps t (e0), t+1 (e1), ...
@@ -282,9 +303,9 @@ __global__ __launch_bounds__(T_THREADS, 4) void k_tile_ll(uint32_t nb, uint32_t 
 #else
 #define TILE_LOOKUP(V, E16)                                                                                      \
     do {                                                                                                         \
-        const uint32_t b__ = (((E16) >> 4) & 1023u) * T_LROW;                                                    \
-        if constexpr (EXPECTED) V = make_double2(s_tab[b__ + ((E16) & 15u)], s_tab[b__ + T_NCODE + ((E16) >> 14)]); \
-        else V = s_tab[b__ + ((E16) & 15u)];                                                                     \
+        const uint32_t b__ = (((E16) >> G::SHIFT) & G::SMASK) * G::LROW;                                         \
+        if constexpr (EXPECTED) V = make_double2(s_tab[b__ + ((E16) & G::CMASK)], s_tab[b__ + G::NCODE + ((E16) >> 14)]); \
+        else V = s_tab[b__ + ((E16) & G::CMASK)];                                                                \
     } while (0)
 #endif
 #define TILE_RD(V, KK)                                                                                           \
@@ -797,6 +818,66 @@ __global__ __launch_bounds__(256) void k_t2_tables(uint32_t n_pairs, const uint3
         const double2 p = ab[l];
         tab2[(uint64_t)l * T2_ROW + sec * 8u] = p.x >= 0.0 ? ov_expected_rec(p.x, p.y, n) : 0.0;
     }
+}
+
+// The same values in the CHUNKED layout of the tier-2 tiles (deep coverage: k_tile_ll<.., geo_t2> reads them out of LDS like the
+// regular tables): [chunk][slot][G::LROW] = the pairs' log-pmfs of totals 5..G::NHI, then E(5..G::NHI).  A deep matrix carries
+// every pair at nearly every locus, so no lists here: blocks [0, gp) take a (locus, pair) per thread, the others a (locus, total)
+// — dense waves that run the same loops (the expected term's recurrence is much longer than a pair's product).  The last slot
+// of a chunk and the slots beyond L are never written (zeroed once at build); a masked locus gets zeros.
+template <bool EXPECTED, class G>
+__global__ __launch_bounds__(256) void k_t2c_tables(uint64_t L, uint32_t gp, const double2 *__restrict__ ab, const double *__restrict__ lf,
+                                                    double *__restrict__ tabc)
+{
+    constexpr uint64_t ELEMS = (uint64_t)G::LROW * G::BL;
+    if (blockIdx.x < gp) {
+        const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+        const uint64_t l = i / G::NCODE;
+        if (l >= L) return;
+        const uint32_t c2 = (uint32_t)(i % G::NCODE);
+        const uint32_t n = 5u + (c2 >= 6u) + (c2 >= 13u) + (c2 >= 21u), r = c2 - t2_code(n, 0u), a = n - r;
+        const double2 p = ab[l];
+        double v = 0.0;
+        if (p.x >= 0.0) {  // (the arithmetic of k_t2_tables: both sides of a pass add the same bits)
+            double num = 1.0, den = 1.0, fa = p.x, fb = p.y, fab = p.x + p.y;
+#pragma unroll
+            for (uint32_t k = 0; k < T2_NMAX; ++k) {
+                const bool on = k < n, isa = k < a;
+                num *= on ? (isa ? fa : fb) : 1.0;
+                den *= on ? fab : 1.0;
+                fa += isa ? 1.0 : 0.0;
+                fb += (on && !isa) ? 1.0 : 0.0;
+                fab += 1.0;
+            }
+            v = (lf[n] - lf[a] - lf[r]) + log(num / den);
+        }
+        tabc[(l / G::BLU) * ELEMS + (l % G::BLU) * G::LROW + c2] = v;
+    } else if (EXPECTED) {
+        constexpr uint32_t NE = G::NHI - G::NLO + 1;
+        const uint64_t i = (uint64_t)(blockIdx.x - gp) * 256 + threadIdx.x;
+        const uint64_t l = i / NE;
+        if (l >= L) return;
+        const uint32_t n = G::NLO + (uint32_t)(i % NE);
+        const double2 p = ab[l];
+        tabc[(l / G::BLU) * ELEMS + (l % G::BLU) * G::LROW + G::NCODE + (n - G::NLO)] = p.x >= 0.0 ? ov_expected_rec(p.x, p.y, n) : 0.0;
+    }
+}
+
+// o[row] += the tier-2 tile pass' partial sums of the row, in group order (the overflow kernels of the side stream wrote o before)
+template <bool EXPECTED>
+__global__ __launch_bounds__(256) void k_t2_tile_add(uint64_t n_rows, uint32_t groups, uint64_t npad, const double *__restrict__ part_ll,
+                                                     const double *__restrict__ part_ell, double *__restrict__ o_ll,
+                                                     double *__restrict__ o_ell)
+{
+    const uint64_t row = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (row >= n_rows) return;
+    double s = 0.0, e = 0.0;
+    for (uint32_t g = 0; g < groups; g++) {
+        s += part_ll[(uint64_t)g * npad + row];
+        if (EXPECTED) e += part_ell[(uint64_t)g * npad + row];
+    }
+    o_ll[row] += s;
+    if (EXPECTED) o_ell[row] += e;
 }
 
 // the two lists, from the static pair histogram: a thread per locus.  COUNT: pairs / sectors of the locus; FILL: at the offsets
@@ -1677,7 +1758,21 @@ __device__ __forceinline__ uint64_t row_lower_bound(const uint64_t *__restrict__
 // in this chunk (stable counting sort: deterministic layout), every 64 of them form a slice of 64 rows [cell, K entries]
 // with K = the slice's longest cell rounded up to odd.  FILL = false: tile size; FILL = true: write slices + header.
 #define TB_BINS 64  // entry counts >= TB_BINS-1 share the last bin (they sort to the end, in cell order)
-template <bool FILL>
+// which entries a tile set takes, and their 16-bit form inside chunk j
+template <class G>
+__device__ __forceinline__ bool geo_take(uint64_t e)
+{
+    const uint32_t n = ENT_ALT(e) + ENT_REF(e);
+    return n - G::NLO <= G::NHI - G::NLO;
+}
+template <class G>
+__device__ __forceinline__ uint16_t geo_encode(uint64_t e, uint32_t j)
+{
+    const uint32_t r = ENT_REF(e), n = ENT_ALT(e) + r;
+    const uint32_t code = G::NLO == 1 ? ent_code(e) : t2_code(n, r);
+    return (uint16_t)(((n - G::NLO) << 14) | ((ENT_IDX(e) - j * G::BLU) << G::SHIFT) | code);
+}
+template <bool FILL, class G = geo_reg>
 __global__ __launch_bounds__(T_BC) void k_tile_build(uint64_t nloc, uint32_t nj, uint64_t tile0,
                                                      const uint64_t *__restrict__ csr_ptr,
                                                      const uint64_t *__restrict__ csr_ent,
@@ -1703,10 +1798,10 @@ __global__ __launch_bounds__(T_BC) void k_tile_build(uint64_t nloc, uint32_t nj,
             lo = beg + toff[row * (nj + 1) + j];
             hi = beg + toff[row * (nj + 1) + j + 1];
         } else {
-            lo = row_lower_bound(csr_ent, beg, end, j * T_BLU);
-            hi = row_lower_bound(csr_ent, lo, end, (j + 1u) * T_BLU);
+            lo = row_lower_bound(csr_ent, beg, end, j * G::BLU);
+            hi = row_lower_bound(csr_ent, lo, end, (j + 1u) * G::BLU);
         }
-        for (uint64_t i = lo; i < hi; i++) len += ent_regular(csr_ent[i]) ? 1u : 0u;
+        for (uint64_t i = lo; i < hi; i++) len += geo_take<G>(csr_ent[i]) ? 1u : 0u;
     }
     __syncthreads();
     // stable counting sort by bin = min(len, TB_BINS-1): rank inside (wave, bin) from ballots
@@ -1770,10 +1865,9 @@ __global__ __launch_bounds__(T_BC) void k_tile_build(uint64_t nloc, uint32_t nj,
     uint32_t k = 0;
     for (uint64_t i = lo; i < hi; i++) {
         const uint64_t e = csr_ent[i];
-        if (ent_regular(e))
-            dst[1 + k++] = (uint16_t)(((ENT_ALT(e) + ENT_REF(e) - 1u) << 14) | ((ENT_IDX(e) - j * T_BLU) << 4) | ent_code(e));
+        if (geo_take<G>(e)) dst[1 + k++] = geo_encode<G>(e, j);
     }
-    for (; k < K; k++) dst[1 + k] = T_NULL;
+    for (; k < K; k++) dst[1 + k] = (uint16_t)(G::BLU << G::SHIFT);  // padding: the chunk's all-zero slot
 }
 
 // Bank-aware order of the entries inside the rows of one slice (option "bank_order"; a wave per slice, lane = row, the slice's rows
@@ -2037,8 +2131,8 @@ __global__ __launch_bounds__(T_BC, 8) void k_tile_build2(uint64_t nloc, uint32_t
 }
 
 // wave per row/column: count entries that are NOT regular (FILL = false) or copy them in order (FILL = true);
-// REST: only those outside tier 2 as well (totals 0 and above 8)
-template <bool FILL, bool REST = false>
+// REST > 0: only those outside the totals 5..REST as well (8: tier 2, i.e. totals 0 and above 8 remain)
+template <bool FILL, int REST = 0>
 __global__ __launch_bounds__(256) void k_ovf_build(uint64_t n_rows, const uint64_t *__restrict__ ptr,
                                                    const uint64_t *__restrict__ ent, uint64_t *__restrict__ optr,
                                                    uint64_t *__restrict__ oent)
@@ -2051,7 +2145,7 @@ __global__ __launch_bounds__(256) void k_ovf_build(uint64_t n_rows, const uint64
         for (uint64_t i0 = beg; i0 < end; i0 += 64) {
             const uint64_t i = i0 + lane;
             const uint64_t e = i < end ? ent[i] : 0;
-            const bool ov = i < end && !ent_regular(e) && !(REST && t2_total(ENT_ALT(e) + ENT_REF(e)));
+            const bool ov = i < end && !ent_regular(e) && !(REST && ENT_ALT(e) + ENT_REF(e) - T2_NMIN <= (uint32_t)REST - T2_NMIN);
             const unsigned long long m = __ballot(ov);
             if (FILL && ov) oent[base + __popcll(m & ((1ull << lane) - 1ull))] = e;
             base += __popcll(m);
@@ -2117,10 +2211,139 @@ void tiled_free(cellector_ctx *c)
     dev_free(c->masked_cnt); dev_free(c->flag_bits); dev_free(c->ovf_tab); dev_free(c->ovf_etab);
     dev_free(c->ovf_sum); dev_free(c->ovf_lp); dev_free(c->ovc_locus); dev_free(c->ovf_tier_row[0]); dev_free(c->ovf_tier_row[1]); dev_free(c->ovf_tier_ent[0]); dev_free(c->ovf_tier_ent[1]); dev_free(c->ovf_tier_val); dev_free(c->ovf_ell_ptr); dev_free(c->ovf_ell); dev_free(c->ovf_nmask); dev_free(c->tile_work); dev_free(c->minlist); dev_free(c->hist_min); dev_free(c->roff); dev_free(c->c4r); dev_free(c->mroff); dev_free(c->mbeg);
     dev_free(c->t2_plist); dev_free(c->t2_slist); dev_free(c->t2_pmask); dev_free(c->hist_all2); dev_free(c->cnt2); dev_free(c->tab2); dev_free(c->ovx_ptr); dev_free(c->ovx_ent); dev_free(c->ovx_locus); dev_free(c->ovx_lp);
+    dev_free(c->tile2_ptr); dev_free(c->tiles2); dev_free(c->thdr2); dev_free(c->tab2c); dev_free(c->part2); dev_free(c->tile_work2); dev_free(c->ovr_ptr); dev_free(c->ovr_ent);
+    c->ovr_n = 0;
+    c->t2_tiles = 0;
     c->ovx_n = 0; c->t2 = false;
     c->mroff_cap = 0;
     c->tiled_ready = false;
     c->ovf_n = 0; c->n_masked_loci = 0;
+}
+
+// Chunk groups of a tile pass (see tiled_build): the count with the shortest modelled makespan of the persistent workgroups.
+static uint32_t tile_groups_for(const cellector_ctx *c, uint32_t nb, uint32_t nj)
+{
+    int ncu = 256;
+    (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, c->device);
+    const uint64_t cols = (nb + T_SB_MAX - 1) / T_SB_MAX;
+    uint64_t groups = 1;
+    double best = 1e300;
+    for (uint64_t g = 1; g <= T_GROUPS_MAX && g <= (uint64_t)nj; g++) {
+        uint64_t per = (uint64_t)ncu / g;
+        if (per < 1) per = 1;
+        if (per > cols) per = cols;
+        const uint64_t rounds = (cols + per - 1) / per, chunks = ((uint64_t)nj + g - 1) / g;
+        const double cost = (double)(rounds * (chunks + 3)) * (1.0 + 0.03 * (g > T_GROUPS ? (double)(g - T_GROUPS) / T_GROUPS : 0.0));
+        if (cost < best) { best = cost; groups = g; }
+    }
+    if (c->tile_groups_opt > 0) groups = (uint64_t)c->tile_groups_opt;  // (A/B runs)
+    if (groups > nj) groups = nj;
+    return (uint32_t)groups;
+}
+
+// ---- tier-2 tiles (deep coverage): a second tile set over the overflow CSR's entries with totals 5..G::NHI ----
+// Built with the per-tile builder (one workgroup per tile, two searches per row in the short overflow rows); the rows keep
+// their file order.  A tile holds all 1024 rows of its block, most of them with one padding entry: 4 bytes per row.
+template <class G>
+static cellector_status t2_tiles_build(cellector_ctx *c)
+{
+    const uint64_t nloc = c->nloc, L = c->L;
+    c->t2_nj = (uint32_t)((L + G::BLU - 1) / G::BLU);
+    if (c->t2_nj == 0) c->t2_nj = 1;
+    c->t2_groups = tile_groups_for(c, c->t_nb, c->t2_nj);
+    c->t2_cpg = (c->t2_nj + c->t2_groups - 1) / c->t2_groups;
+    c->t2_groups = (c->t2_nj + c->t2_cpg - 1) / c->t2_cpg;
+    const uint64_t nt = (uint64_t)c->t_nb * c->t2_nj, maxg = 1ull << 30;
+    CHK(dev_alloc(c, &c->tile2_ptr, nt + 1));
+    HIPCHK(c, hipMemsetAsync(c->tile2_ptr + nt, 0, 8, c->stream));
+    for (uint64_t t0 = 0; t0 < nt; t0 += maxg) {
+        const uint64_t g = nt - t0 < maxg ? nt - t0 : maxg;
+        hipLaunchKernelGGL((k_tile_build<false, G>), dim3((unsigned)g), dim3(T_BC), 0, c->stream, nloc, c->t2_nj, t0, c->ovf_ptr, c->ovf_ent,
+                           c->tile2_ptr, (uint16_t *)nullptr, (uint16_t *)nullptr, (const uint32_t *)nullptr);
+    }
+    HIPCHK(c, hipGetLastError());
+    uint64_t elems = 0;
+    CHK(dev_exclusive_scan_u64(c, c->tile2_ptr, nt + 1, &elems));
+    CHK(dev_alloc(c, &c->tiles2, elems + 64));  // tail pad: the 16-byte load of the last row runs past its end
+    CHK(dev_alloc(c, &c->thdr2, nt * T_HDR));
+    for (uint64_t t0 = 0; t0 < nt; t0 += maxg) {
+        const uint64_t g = nt - t0 < maxg ? nt - t0 : maxg;
+        hipLaunchKernelGGL((k_tile_build<true, G>), dim3((unsigned)g), dim3(T_BC), 0, c->stream, nloc, c->t2_nj, t0, c->ovf_ptr, c->ovf_ent,
+                           c->tile2_ptr, c->tiles2, c->thdr2, (const uint32_t *)nullptr);
+    }
+    HIPCHK(c, hipGetLastError());
+    const uint64_t tab_elems = (uint64_t)c->t2_nj * G::LROW * G::BL + 4 * T_THREADS;  // tail pad: the partial last table load
+    CHK(dev_alloc(c, &c->tab2c, tab_elems));
+    HIPCHK(c, hipMemsetAsync(c->tab2c, 0, tab_elems * sizeof(double), c->stream));  // (zero slots and the slots beyond L stay zero)
+    CHK(dev_alloc(c, &c->part2, 3ull * 2 * c->t2_groups * c->t_npad));
+    CHK(dev_alloc(c, &c->tile_work2, T_GROUPS_MAX));
+    // what the tiles leave to the per-entry kernel (totals 0 and above G::NHI), as a by-cell CSR of its own: walking the whole
+    // overflow CSR and skipping the tiles' entries kept that kernel's waves as long as before (a wave waits for its slowest lane)
+    CHK(dev_alloc(c, &c->ovr_ptr, nloc + 1));
+    HIPCHK(c, hipMemsetAsync(c->ovr_ptr + nloc, 0, 8, c->stream));
+    hipLaunchKernelGGL((k_ovf_build<false, (int)G::NHI>), dim3(gcap(nloc, 4)), dim3(256), 0, c->stream, nloc, c->ovf_ptr, c->ovf_ent, c->ovr_ptr,
+                       (uint64_t *)nullptr);
+    CHK(dev_exclusive_scan_u64(c, c->ovr_ptr, nloc + 1, &c->ovr_n));
+    CHK(dev_alloc(c, &c->ovr_ent, c->ovr_n));
+    hipLaunchKernelGGL((k_ovf_build<true, (int)G::NHI>), dim3(gcap(nloc, 4)), dim3(256), 0, c->stream, nloc, c->ovf_ptr, c->ovf_ent, c->ovr_ptr,
+                       c->ovr_ent);
+    HIPCHK(c, hipGetLastError());
+    return CELLECTOR_OK;
+}
+
+// one tier-2 tile pass on the main stream: this pass' chunked tables, then the tile kernel over the second tile set
+template <class G>
+static cellector_status t2_tiles_pass_g(cellector_ctx *c, const double2 *ab, int set, bool expected)
+{
+    constexpr uint32_t NE = G::NHI - G::NLO + 1;
+    const unsigned gp = gcap(c->L * G::NCODE, 256, 0x7fffffffu), ge = expected ? gcap(c->L * NE, 256, 0x7fffffffu) : 0u;
+    if (expected)
+        hipLaunchKernelGGL((k_t2c_tables<true, G>), dim3(gp + ge), dim3(256), 0, c->stream, c->L, gp, ab, (const double *)c->lf, c->tab2c);
+    else
+        hipLaunchKernelGGL((k_t2c_tables<false, G>), dim3(gp), dim3(256), 0, c->stream, c->L, gp, ab, (const double *)c->lf, c->tab2c);
+    double *part_ll = c->part2 + (uint64_t)set * 2 * c->t2_groups * c->t_npad;
+    double *part_ell = part_ll + (uint64_t)c->t2_groups * c->t_npad;
+    int ncu = 256;
+    (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, c->device);
+    int sb = T_SB_MAX;
+    while (sb > 2 && (uint64_t)((c->t_nb + sb - 1) / sb) * c->t2_groups * 10 < (uint64_t)ncu * 9) sb >>= 1;
+    const uint32_t n_cols = (c->t_nb + sb - 1) / sb;
+    uint32_t per_group = (uint32_t)ncu / c->t2_groups;
+    if (per_group < 1) per_group = 1;
+    if (per_group > n_cols) per_group = n_cols;
+    const dim3 grid(per_group * c->t2_groups);
+    HIPCHK(c, hipMemsetAsync(c->tile_work2, 0, T_GROUPS_MAX * sizeof(uint32_t), c->stream));
+#define LAUNCH_TILE2(E, S)                                                                                                 \
+    hipLaunchKernelGGL((k_tile_ll<E, S, G>), grid, dim3(T_THREADS), 0, c->stream, c->t_nb, c->t2_nj, c->t2_cpg, c->t2_groups, n_cols, \
+                       c->tile_work2, (const uint16_t *)c->thdr2, (const uint16_t *)c->tiles2, (const double *)c->tab2c, c->t_npad,    \
+                       part_ll, part_ell)
+    if (expected) {
+        if (sb == 4) LAUNCH_TILE2(true, 4); else LAUNCH_TILE2(true, 2);
+    } else {
+        if (sb == 4) LAUNCH_TILE2(false, 4); else LAUNCH_TILE2(false, 2);
+    }
+#undef LAUNCH_TILE2
+    HIPCHK(c, hipGetLastError());
+    return CELLECTOR_OK;
+}
+static cellector_status t2_tiles_pass(cellector_ctx *c, const double2 *ab, int set, bool expected)
+{
+    if (!c->t2_tiles) return CELLECTOR_OK;
+    return c->t2_tiles == 8 ? t2_tiles_pass_g<geo_t2<8>>(c, ab, set, expected) : t2_tiles_pass_g<geo_t2<6>>(c, ab, set, expected);
+}
+// ... and its partial sums added to the overflow sums of the set (behind the side stream's kernels, which write those)
+static cellector_status t2_tiles_add(cellector_ctx *c, int set, bool expected)
+{
+    if (!c->t2_tiles) return CELLECTOR_OK;
+    double *part_ll = c->part2 + (uint64_t)set * 2 * c->t2_groups * c->t_npad, *part_ell = part_ll + (uint64_t)c->t2_groups * c->t_npad;
+    double *o_ll = c->ovf_sum + (uint64_t)set * 2 * c->nloc, *o_ell = o_ll + c->nloc;
+    const unsigned g = gcap(c->nloc, 256, 0x7fffffffu);
+    if (expected)
+        hipLaunchKernelGGL(k_t2_tile_add<true>, dim3(g), dim3(256), 0, c->stream, c->nloc, c->t2_groups, c->t_npad, part_ll, part_ell, o_ll, o_ell);
+    else
+        hipLaunchKernelGGL(k_t2_tile_add<false>, dim3(g), dim3(256), 0, c->stream, c->nloc, c->t2_groups, c->t_npad, part_ll, part_ell, o_ll, o_ell);
+    HIPCHK(c, hipGetLastError());
+    return CELLECTOR_OK;
 }
 
 cellector_status tiled_build(cellector_ctx *c)
@@ -2145,24 +2368,7 @@ cellector_status tiled_build(cellector_ctx *c)
     // the second half empty), 2: 0.48, 1: 0.73 (49 CUs busy).  Groups used to be multiples of 8 so that a group's workgroups
     // shared an XCD's L2 for the table reads (workgroup i runs on XCD i mod 8): the figures above show no such need — the
     // workgroups of a group walk the chunks in step, a table chunk is fetched once per XCD either way.
-    {
-        int ncu = 256;
-        (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, c->device);
-        const uint64_t cols = (c->t_nb + T_SB_MAX - 1) / T_SB_MAX;
-        uint64_t groups = 1;
-        double best = 1e300;
-        for (uint64_t g = 1; g <= T_GROUPS_MAX && g <= (uint64_t)c->t_nj; g++) {
-            uint64_t per = (uint64_t)ncu / g;
-            if (per < 1) per = 1;
-            if (per > cols) per = cols;
-            const uint64_t rounds = (cols + per - 1) / per, chunks = ((uint64_t)c->t_nj + g - 1) / g;
-            const double cost = (double)(rounds * (chunks + 3)) * (1.0 + 0.03 * (g > T_GROUPS ? (double)(g - T_GROUPS) / T_GROUPS : 0.0));
-            if (cost < best) { best = cost; groups = g; }
-        }
-        if (c->tile_groups_opt > 0) groups = (uint64_t)c->tile_groups_opt;  // (A/B runs)
-        if (groups > c->t_nj) groups = c->t_nj;
-        c->t_groups = (uint32_t)groups;
-    }
+    c->t_groups = tile_groups_for(c, c->t_nb, c->t_nj);
     c->t_cpg = (c->t_nj + c->t_groups - 1) / c->t_groups;
     c->t_groups = (c->t_nj + c->t_cpg - 1) / c->t_cpg;
     c->t_npad = (uint64_t)c->t_nb * T_BC;
@@ -2280,6 +2486,11 @@ cellector_status tiled_build(cellector_ctx *c)
     // evaluations per locus: locus pass 1.6 -> 1.0 ms at 10^6 cells x 200k loci deep); its cell side stays with the arithmetic
     // kernel — 2.3e8 lookups of a line each out of a 77 MB table cost more than evaluating the entries (measured: 9.8 vs 6.1 ms).
     c->t2 = c->ovf_n != 0 && L != 0 && L < (1ull << 27) /* the pair list's keys */ && (c->t2_opt >= 0 ? c->t2_opt != 0 : true);
+    // tier-2 tiles: the cell side of the totals 5..8 (or 5..6) of a deep matrix walks tiles of its own (t2_tiles_build)
+    c->t2_tiles = 0;
+    if (c->ovf_deep && c->ovf_deep_wide && c->ovf_n && nloc && L) c->t2_tiles = c->t2_tiles_opt < 0 ? 8 : c->t2_tiles_opt;
+    if (c->t2_tiles == 8) CHK(t2_tiles_build<geo_t2<8>>(c));
+    else if (c->t2_tiles == 6) CHK(t2_tiles_build<geo_t2<6>>(c));
     CHK(dev_alloc(c, &c->ovf_sum, 3 * 2 * nloc));
     CHK(dev_alloc(c, &c->ovf_tab, L * OV_ROW));
     CHK(dev_alloc(c, &c->ovc_locus, c->ovf_n));
@@ -2324,13 +2535,13 @@ cellector_status tiled_build(cellector_ctx *c)
         }
         CHK(dev_alloc(c, &c->ovx_ptr, L + 1));
         HIPCHK(c, hipMemsetAsync(c->ovx_ptr + L, 0, 8, c->stream));
-        hipLaunchKernelGGL((k_ovf_build<false, true>), dim3(gcap(L, 4)), dim3(256), 0, c->stream, L, c->ovc_ptr, c->ovc_ent, c->ovx_ptr,
+        hipLaunchKernelGGL((k_ovf_build<false, 8>), dim3(gcap(L, 4)), dim3(256), 0, c->stream, L, c->ovc_ptr, c->ovc_ent, c->ovx_ptr,
                            (uint64_t *)nullptr);
         CHK(dev_exclusive_scan_u64(c, c->ovx_ptr, L + 1, &c->ovx_n));
         CHK(dev_alloc(c, &c->ovx_ent, c->ovx_n));
         CHK(dev_alloc(c, &c->ovx_locus, c->ovx_n));
         CHK(dev_alloc(c, &c->ovx_lp, c->ovx_n));
-        hipLaunchKernelGGL((k_ovf_build<true, true>), dim3(gcap(L, 4)), dim3(256), 0, c->stream, L, c->ovc_ptr, c->ovc_ent, c->ovx_ptr,
+        hipLaunchKernelGGL((k_ovf_build<true, 8>), dim3(gcap(L, 4)), dim3(256), 0, c->stream, L, c->ovc_ptr, c->ovc_ent, c->ovx_ptr,
                            c->ovx_ent);
         if (c->ovx_n)
             hipLaunchKernelGGL(k_ovf_locus_ids, dim3(gcap(L, 4)), dim3(256), 0, c->stream, L, c->ovx_ptr, c->ovx_locus);
@@ -2478,8 +2689,8 @@ static void launch_overflow_cell(cellector_ctx *c, hipStream_t st, const double2
         // kernel and disturbs it less (cfg4: 2.83 -> 2.78 ms per iteration); a small shard's tile kernel is too short for that.
         const size_t lds_req = deep ? 0 : c->side_lds >= 0 ? (size_t)c->side_lds : (st == c->side && c->nloc >= (1ull << 19) ? 5000 : 0);
         if (deep && c->ovf_deep_wide)
-            hipLaunchKernelGGL(k_ovf_cell_wide<true>, dim3(gcap(c->nloc * LF_LANES, 256, 0x7fffffffu)), dim3(256), 0, st, c->nloc, c->ovf_ptr,
-                               c->ovf_ent, ab, c->lf, c->ovf_etab, c->ovf_tab, o_ll, o_ell);
+            hipLaunchKernelGGL(k_ovf_cell_wide<true>, dim3(gcap(c->nloc * LF_LANES, 256, 0x7fffffffu)), dim3(256), 0, st, c->nloc, c->t2_tiles ? c->ovr_ptr : c->ovf_ptr,
+                               c->t2_tiles ? c->ovr_ent : c->ovf_ent, ab, c->lf, c->ovf_etab, c->ovf_tab, o_ll, o_ell);
         else if (deep)
             hipLaunchKernelGGL((k_ovf_cell_direct<true, false, true>), dim3(g), dim3(256), 0, st, c->nloc, c->ovf_ell_ptr, c->ovf_ell, ab,
                                c->lf, c->ovf_etab, c->ovf_tab, o_ll, o_ell);
@@ -2500,8 +2711,8 @@ static void launch_overflow_cell(cellector_ctx *c, hipStream_t st, const double2
         }
     } else {
         if (deep && c->ovf_deep_wide)
-            hipLaunchKernelGGL(k_ovf_cell_wide<false>, dim3(gcap(c->nloc * LF_LANES, 256, 0x7fffffffu)), dim3(256), 0, st, c->nloc, c->ovf_ptr,
-                               c->ovf_ent, ab, c->lf, c->ovf_etab, c->ovf_tab, o_ll, o_ell);
+            hipLaunchKernelGGL(k_ovf_cell_wide<false>, dim3(gcap(c->nloc * LF_LANES, 256, 0x7fffffffu)), dim3(256), 0, st, c->nloc, c->t2_tiles ? c->ovr_ptr : c->ovf_ptr,
+                               c->t2_tiles ? c->ovr_ent : c->ovf_ent, ab, c->lf, c->ovf_etab, c->ovf_tab, o_ll, o_ell);
         else if (deep)
             hipLaunchKernelGGL((k_ovf_cell_direct<false, false, true>), dim3(g), dim3(256), 0, st, c->nloc, c->ovf_ell_ptr, c->ovf_ell, ab, c->lf,
                                c->ovf_etab, c->ovf_tab, o_ll, o_ell);
@@ -2660,6 +2871,7 @@ static cellector_status cell_pass_launch(cellector_ctx *c, const double2 *ab, bo
         // every launch ahead of it (five on the side stream) would be ~10 us of idle GPU
         CHK(side_fork(c));
         CHK(run_tile_pass(c, 0, c->compute_expected));
+        CHK(t2_tiles_pass(c, ab, 0, c->compute_expected));
         launch_overflow_cell(c, c->side, ab, 0, c->compute_expected);
         HIPCHK(c, hipEventRecord(c->ev_join, c->side));
         if (for_em && c->overlap == 1) {  // the locus side's values right behind the cell side, beside the tile kernel
@@ -2681,6 +2893,7 @@ static cellector_status cell_pass_launch(cellector_ctx *c, const double2 *ab, bo
             if (for_em) launch_overflow_locus_values(c, c->stream, ab);
         }
         CHK(run_tile_pass(c, 0, c->compute_expected));
+        CHK(t2_tiles_pass(c, ab, 0, c->compute_expected));
     }
     return CELLECTOR_OK;
 }
@@ -2697,6 +2910,7 @@ cellector_status tiled_cell_pass(cellector_ctx *c, const double2 *ab, double *no
         HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
         c->cell_join_pending = false;
     }
+    CHK(t2_tiles_add(c, 0, c->compute_expected));
     double *part_ll = c->part, *part_ell = c->part + (uint64_t)c->t_groups * c->t_npad;
     const double *o_ll = ovf ? c->ovf_sum : nullptr, *o_ell = ovf ? c->ovf_sum + c->nloc : nullptr;
     const unsigned grid = gcap((c->nloc + 1) / 2, 256, 0x7fffffffu);
@@ -2840,12 +3054,15 @@ cellector_status tiled_posteriors(cellector_ctx *c, double mf0, double lp_min, d
         CHK(side_fork(c));
         for (int set = 0; set < 3; set++) launch_overflow_cell(c, c->side, c->ab3 + (uint64_t)set * L, set, false);
         for (int set = 0; set < 3; set++) CHK(run_tile_pass(c, set, false));
+        for (int set = 0; set < 3; set++) CHK(t2_tiles_pass(c, c->ab3 + (uint64_t)set * L, set, false));
         CHK(side_join(c));
     } else {
         if (ovf)
             for (int set = 0; set < 3; set++) launch_overflow_cell(c, c->stream, c->ab3 + (uint64_t)set * L, set, false);
         for (int set = 0; set < 3; set++) CHK(run_tile_pass(c, set, false));
+        for (int set = 0; set < 3; set++) CHK(t2_tiles_pass(c, c->ab3 + (uint64_t)set * L, set, false));
     }
+    for (int set = 0; set < 3; set++) CHK(t2_tiles_add(c, set, false));
     hipLaunchKernelGGL(k_posterior_finalize, dim3(gcap(c->nloc, 256, 0x7fffffffu)), dim3(256), 0, c->stream, c->nloc,
                        ovf ? c->ovf_sum : (const double *)nullptr, c->t_groups, c->t_npad, c->part, lp_min, lp_maj, lp_dbl, c->post);
     timer_end(c, CELLECTOR_K_POSTERIOR);

@@ -224,15 +224,19 @@ def test_overflow_side_stream_equals_in_stream(mods):
     # (the deep form has two kernels: 16 lanes per row — the default — and a thread per row)
     # (t2: the entries with totals 5..8 through per-(locus, pair) tables — the default unless the matrix is deep — or, 0, one by
     # one like the other totals: same values within rounding)
-    variants = ((1, -1, 0, 1, -1), (0, -1, 0, 1, -1), (2, -1, 0, 1, -1), (1, 5000, 0, 1, -1), (1, -1, 0, 1, 0), (1, -1, -1, 1, -1),
-                (0, -1, 1, 1, -1), (1, -1, 1, 0, -1), (1, -1, 1, 1, 1), (0, -1, 1, 1, 1))
-    for ov, lds, deep, wide, t2 in variants:
+    # (t2_tiles: the deep form's cell side of the totals 5..8 — the default — or 5..6 through a second tile set with chunk tables
+    # in LDS, or, 0, evaluated one by one by the 16-lanes-per-row kernel like the other totals: same values within rounding)
+    variants = ((1, -1, 0, 1, -1, -1), (0, -1, 0, 1, -1, -1), (2, -1, 0, 1, -1, -1), (1, 5000, 0, 1, -1, -1), (1, -1, 0, 1, 0, -1),
+                (1, -1, -1, 1, -1, -1), (0, -1, 1, 1, -1, -1), (1, -1, 1, 0, -1, -1), (1, -1, 1, 1, 1, -1), (0, -1, 1, 1, 1, -1),
+                (1, -1, 1, 1, -1, 0), (1, -1, 1, 1, -1, 6), (0, -1, 1, 1, 1, 6), (1, -1, 1, 1, 0, 8))
+    for ov, lds, deep, wide, t2, tt in variants:
         g = mods["Cellector"](0)
         g.set_option("overlap", ov)
         g.set_option("side_lds", lds)
         g.set_option("ovf_deep", deep)
         g.set_option("ovf_deep_wide", wide)
         g.set_option("t2", t2)
+        g.set_option("t2_tiles", tt)
         g.load_coo(L, N, lo, ce, al, re)
         o = mods["ob"].Oracle.from_coo(L, N, lo, ce, al, re)
         run = []
@@ -258,7 +262,7 @@ def test_overflow_side_stream_equals_in_stream(mods):
         for k in post_a:
             assert same(post_a[k], post_b[k]), (vi, k)
     # the deep-form runs beside the lookup kernel / in one stream agree to the bit, without and with tier-2 tables
-    for i, j in ((5, 6), (8, 9)):
+    for i, j in ((5, 6), (8, 9), (11, 12)):
         for (ca, la), (cb, lb) in zip(outs[i][0], outs[j][0]):
             for k in ca:
                 assert np.array_equal(ca[k], cb[k]), (i, j, k)

@@ -62,7 +62,7 @@ def main():
             opts = {"locus_mode": int(rng.choice([0, 0, 1, 2])), "overlap": int(rng.choice([1, 1, 0, 2])),
                     "compact_bits": int(rng.choice([0, 0, 32])), "side_lds": int(rng.choice([-1, -1, 5000])),
                     "ovf_deep": int(rng.choice([-1, -1, 0, 1])), "ovf_deep_wide": int(rng.choice([1, 1, 0])), "t2": int(rng.choice([-1, -1, 0, 1])),
-                    "bank_order": int(rng.choice([1, 1, 1, 0]))}
+                    "bank_order": int(rng.choice([1, 1, 1, 0])), "t2_tiles": int(rng.choice([-1, -1, 0, 6, 8]))}
         two_shards = engine == 2 and N >= 2 and rng.random() < 0.25
         desc = f"case {case}: N={N} L={L} d={dens:.3g} min={minority} dbl={doublet} nnz={len(lo)} engine={engine} {opts}" \
                f"{' 2 shards' if two_shards else ''} filter=({min_alt},{min_ref})"
