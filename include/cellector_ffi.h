@@ -107,7 +107,11 @@ cellector_status cellector_set_stream(cellector_ctx *ctx, void *hip_stream);
  * histograms for runs of 4 Mi cells and more on three or more ranks, else the gather; same bits either way),
  * "balance" (multi-device ctx, default 1: see cellector_set_partition), "ref_arith" (engine 1: every entry with the
  * reference's own ln_gamma arithmetic, stats.rs:41-53, instead of the exact product form), "t2" / "t2_waves" (engine 2:
- * the entries with totals 5..8 through per-(locus, pair) tables, default on unless the matrix has deep coverage). */
+ * the entries with totals 5..8 through per-(locus, pair) tables, default on unless the matrix has deep coverage),
+ * "bank_order" (engine 2, default 1: the tile builder orders every row's entries and the rows of a slice against LDS bank
+ * conflicts; 0 keeps file order, the layout whose per-cell sums do not depend on which cells share a shard),
+ * "t2_tiles" (engine 2, deep coverage: the cell side of the totals 5..8 (8, the default of a matrix with more than 3 % of
+ * its entries outside 1..4), or 5..6 (6), walks a second tile set with chunk tables in LDS; 0: evaluated entry by entry). */
 cellector_status cellector_set_option(cellector_ctx *ctx, const char *key, int64_t value);
 
 /* ---- sharding (before ingest) --------------------------------------------------------------- */
