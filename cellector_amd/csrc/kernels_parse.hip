@@ -15,6 +15,7 @@
 #include <unistd.h>
 #include <zlib.h>
 
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <mutex>
@@ -257,11 +258,98 @@ struct FileBytes {
 };
 #define FB_HEAD (1u << 20)
 
+// A ".gz" whose members all carry the BGZF extra field (bgzip: blocks of at most 64 KB, each a gzip member with its own
+// compressed size in a 'B','C' subfield — the reference's MultiGzDecoder reads such a file like any multi-member gzip,
+// load_data.rs:246) is inflated block-parallel: the member boundaries are found by hopping over the size fields, the
+// output offsets are the prefix sums of the members' ISIZE trailers, and host threads inflate ranges of blocks straight
+// into place (raw deflate, CRC-32 and length of every block checked like gzread does).  A single zlib stream inflates at
+// ~0.35 GB/s of text; a plain gzip file has no such index and keeps the serial path below.
+struct BgzfBlock { size_t off, clen; uint32_t xlen, isize; size_t out; };
+bool bgzf_index(const uint8_t *f, size_t n, std::vector<BgzfBlock> *blocks, size_t *total)
+{
+    size_t pos = 0, out = 0;
+    while (pos < n) {
+        if (n - pos < 18 || f[pos] != 0x1f || f[pos + 1] != 0x8b || f[pos + 2] != 8 || !(f[pos + 3] & 4)) return false;
+        if (f[pos + 3] & ~4u) return false;  // (name / comment / header CRC: not what bgzip writes — leave it to zlib)
+        const uint32_t xlen = f[pos + 10] | ((uint32_t)f[pos + 11] << 8);
+        if (n - pos < 12 + (size_t)xlen + 8) return false;
+        uint32_t bsize = 0;
+        bool have = false;
+        for (size_t q = pos + 12, e = pos + 12 + xlen; q + 4 <= e;) {
+            const uint32_t slen = f[q + 2] | ((uint32_t)f[q + 3] << 8);
+            if (f[q] == 'B' && f[q + 1] == 'C' && slen == 2 && q + 6 <= e) { bsize = f[q + 4] | ((uint32_t)f[q + 5] << 8); have = true; }
+            q += 4 + slen;
+        }
+        const size_t clen = (size_t)bsize + 1;
+        if (!have || clen < 12 + (size_t)xlen + 8 || n - pos < clen) return false;
+        const uint8_t *tr = f + pos + clen - 4;
+        const uint32_t isize = tr[0] | ((uint32_t)tr[1] << 8) | ((uint32_t)tr[2] << 16) | ((uint32_t)tr[3] << 24);
+        blocks->push_back({pos, clen, xlen, isize, out});
+        out += isize;
+        pos += clen;
+    }
+    *total = out;
+    return !blocks->empty();
+}
+bool bgzf_inflate(const uint8_t *f, const std::vector<BgzfBlock> &blocks, uint8_t *dst)
+{
+    unsigned nt = std::thread::hardware_concurrency();
+    if (nt < 1) nt = 1;
+    if (nt > 32) nt = 32;
+    if ((size_t)nt > blocks.size()) nt = (unsigned)blocks.size();
+    std::atomic<bool> ok(true);
+    auto work = [&](size_t b0, size_t b1) {
+        z_stream z;
+        memset(&z, 0, sizeof z);
+        if (inflateInit2(&z, -15) != Z_OK) { ok = false; return; }
+        for (size_t b = b0; b < b1 && ok; b++) {
+            const BgzfBlock &k = blocks[b];
+            z.next_in = const_cast<Bytef *>(f + k.off + 12 + k.xlen);
+            z.avail_in = (uInt)(k.clen - 12 - k.xlen - 8);
+            z.next_out = dst + k.out;
+            z.avail_out = k.isize;
+            const int r = k.isize || z.avail_in ? inflate(&z, Z_FINISH) : Z_STREAM_END;
+            const uint8_t *tr = f + k.off + k.clen - 8;
+            const uint32_t crc = tr[0] | ((uint32_t)tr[1] << 8) | ((uint32_t)tr[2] << 16) | ((uint32_t)tr[3] << 24);
+            if (r != Z_STREAM_END || z.avail_out != 0 || (uint32_t)crc32(crc32(0L, Z_NULL, 0), dst + k.out, k.isize) != crc) ok = false;
+            inflateReset(&z);
+        }
+        inflateEnd(&z);
+    };
+    std::vector<std::thread> th;
+    const size_t per = (blocks.size() + nt - 1) / nt;
+    for (unsigned t = 1; t < nt; t++) th.emplace_back(work, std::min(blocks.size(), t * per), std::min(blocks.size(), (t + 1) * per));
+    work(0, std::min(blocks.size(), per));
+    for (auto &t : th) t.join();
+    return ok;
+}
+
 // reader (load_data.rs:240-251): ".gz" by extension (multi-member), plain otherwise
 bool load_bytes(const char *path, FileBytes *fb)
 {
     const size_t n = strlen(path);
     if (n >= 3 && strcmp(path + n - 3, ".gz") == 0) {
+        {   // block-compressed (bgzip)?  then in parallel
+            const int fd = open(path, O_RDONLY);
+            struct stat st;
+            if (fd >= 0 && fstat(fd, &st) == 0 && st.st_size > 0 && !getenv("CELLECTOR_NO_BGZF")) {
+                void *m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+                if (m != MAP_FAILED) {
+                    std::vector<BgzfBlock> blocks;
+                    size_t total = 0;
+                    bool done = false;
+                    if (bgzf_index((const uint8_t *)m, (size_t)st.st_size, &blocks, &total)) {
+                        fb->owned.resize(total ? total : 1);
+                        done = bgzf_inflate((const uint8_t *)m, blocks, fb->owned.data());
+                        if (done) { fb->data = fb->owned.data(); fb->size = total; }
+                    }
+                    munmap(m, (size_t)st.st_size);
+                    if (done) { close(fd); return true; }
+                    fb->owned.clear();  // (a damaged block: the serial reader below reports what zlib makes of the file)
+                }
+            }
+            if (fd >= 0) close(fd);
+        }
         gzFile gz = gzopen(path, "rb");
         if (!gz) return false;
         gzbuffer(gz, 1 << 20);
@@ -270,7 +358,11 @@ bool load_bytes(const char *path, FileBytes *fb)
         for (;;) {
             if (len == cap) fb->owned.resize(cap *= 2);
             const int got = gzread(gz, fb->owned.data() + len, (unsigned)std::min<size_t>(cap - len, 1u << 30));
-            if (got <= 0) break;
+            if (got < 0) {  // a damaged stream (CRC, truncated member): the reference's decoder fails the read as well
+                gzclose(gz);
+                return false;
+            }
+            if (got == 0) break;
             len += (size_t)got;
         }
         gzclose(gz);

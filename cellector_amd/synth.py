@@ -135,6 +135,22 @@ def write_mtx_pair(directory, total_loci, total_cells, locus0, cell0, alt, ref, 
     return paths["alt"], paths["ref"]
 
 
+def bgzf_compress(data, block=0xff00, eof_block=True):
+    """`data` as a BGZF file (what bgzip writes): gzip members of at most 64 KB of text, each with the 'BC' extra subfield that
+    holds the member's size - 1, and the empty end-of-file member."""
+    import struct
+    import zlib
+    out = bytearray()
+    pieces = [data[i:i + block] for i in range(0, len(data), block)] + ([b""] if eof_block else [])
+    for piece in pieces:
+        c = zlib.compressobj(6, zlib.DEFLATED, -15)
+        body = c.compress(piece) + c.flush()
+        bsize = 12 + 6 + len(body) + 8 - 1
+        out += b"\x1f\x8b\x08\x04" + b"\0\0\0\0" + b"\x00\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, bsize)
+        out += body + struct.pack("<II", zlib.crc32(piece) & 0xffffffff, len(piece))
+    return bytes(out)
+
+
 def write_barcodes(path, total_cells):
     with _open(path, "wt") as f:
         for i in range(total_cells):

@@ -432,6 +432,35 @@ def test_mtx_files_plain_and_gz(mods, tmp_path):
         sg, so = g.em_iteration(5.0), o.em_iteration(5.0)
         _check_iteration(g, o, sg, so)
         g.close()
+    # block-compressed input (bgzip: every gzip member carries its own size — inflated block-parallel), the same file with a
+    # plain gzip member appended (no index: the serial reader), and a damaged block (an error, never silent garbage)
+    import gzip as _gzip
+    a_plain, r_plain = str(tmp_path / "plain" / "alt.mtx"), str(tmp_path / "plain" / "ref.mtx")
+    os.makedirs(tmp_path / "bgzf", exist_ok=True)
+    o = mods["ob"].Oracle.from_mtx(a_plain, r_plain)
+    for variant in ("bgzf", "mixed"):
+        paths = []
+        for src in (a_plain, r_plain):
+            text = open(src, "rb").read()
+            cut = len(text) * 2 // 3 if variant == "mixed" else len(text)
+            blob = mods["synth"].bgzf_compress(text[:cut], block=4000 if variant == "bgzf" else 0xff00, eof_block=variant == "bgzf")
+            if variant == "mixed":
+                blob += _gzip.compress(text[cut:])
+            dst = str(tmp_path / "bgzf" / (variant + "_" + os.path.basename(src) + ".gz"))
+            open(dst, "wb").write(blob)
+            assert _gzip.decompress(blob) == text  # (a valid multi-member gzip either way)
+            paths.append(dst)
+        g = mods["Cellector"](0)
+        g.load_mtx(paths[0], paths[1])
+        _check_matrix(g, o)
+        g.close()
+    blob = bytearray(open(str(tmp_path / "bgzf" / "bgzf_alt.mtx.gz"), "rb").read())
+    blob[len(blob) // 2] ^= 0x55
+    open(str(tmp_path / "bgzf" / "broken_alt.mtx.gz"), "wb").write(bytes(blob))
+    g = mods["Cellector"](0)
+    with pytest.raises(mods["ffi"].CellectorError):
+        g.load_mtx(str(tmp_path / "bgzf" / "broken_alt.mtx.gz"), str(tmp_path / "bgzf" / "bgzf_ref.mtx.gz"))
+    g.close()
     g = mods["Cellector"](0)
     with pytest.raises(mods["ffi"].CellectorError) as ei:
         g.load_mtx(str(tmp_path / "missing.mtx"), str(tmp_path / "missing.mtx"))

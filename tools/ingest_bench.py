@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--loci", type=int, default=50000)
     ap.add_argument("--density", type=float, default=0.01)
     ap.add_argument("--gz", action="store_true")
+    ap.add_argument("--bgzf", action="store_true", help="block-compressed .gz (what bgzip writes): inflated block-parallel")
     ap.add_argument("--no-oracle", action="store_true")
     ap.add_argument("--engine2-only", action="store_true")
     args = ap.parse_args()
@@ -48,21 +49,25 @@ def main():
     locus, cell, alt, ref = locus[order] + 1, cell[order] + 1, alt[order], ref[order]
     del order
     d = tempfile.mkdtemp(prefix="cellector_ingest_")
-    ext = ".mtx.gz" if args.gz else ".mtx"
+    ext = ".mtx.gz" if (args.gz or args.bgzf) else ".mtx"
     paths = {}
     for name, vals in (("alt", alt), ("ref", ref)):
         p = os.path.join(d, name + ext)
         hdr = f"%%MatrixMarket matrix coordinate real general\n% written by sprs\n{L} {N} {len(locus)}\n"
-        plain = p[:-3] if args.gz else p
+        plain = p[:-3] if (args.gz or args.bgzf) else p
         vals = np.ascontiguousarray(vals)
         rc = fast.fastmtx_write(plain.encode(), hdr.encode(), len(locus), locus.ctypes.data, cell.ctypes.data, vals.ctypes.data)
         assert rc == 0, "mtx write failed"
-        if args.gz:
+        if args.bgzf:
+            from cellector_amd import synth
+            open(p, "wb").write(synth.bgzf_compress(open(plain, "rb").read()))
+            os.remove(plain)
+        elif args.gz:
             subprocess.check_call(["gzip", "-1", "-f", plain])
         paths[name] = p
     t_gen = time.perf_counter() - t_gen
     size = sum(os.path.getsize(p) for p in paths.values())
-    out = {"cells": N, "loci": L, "entries": int(len(locus)), "text_bytes": int(size), "gz": args.gz,
+    out = {"cells": N, "loci": L, "entries": int(len(locus)), "text_bytes": int(size), "gz": args.gz, "bgzf": args.bgzf,
            "generate_and_write_s": t_gen}
     n_entries = int(len(locus))
     del locus, cell, alt, ref
