@@ -284,6 +284,7 @@ bool bgzf_index(const uint8_t *f, size_t n, std::vector<BgzfBlock> *blocks, size
         if (!have || clen < 12 + (size_t)xlen + 8 || n - pos < clen) return false;
         const uint8_t *tr = f + pos + clen - 4;
         const uint32_t isize = tr[0] | ((uint32_t)tr[1] << 8) | ((uint32_t)tr[2] << 16) | ((uint32_t)tr[3] << 24);
+        if (isize > 65536u) return false;  // (bgzip never puts more than 64 KB into a block: not BGZF, leave it to zlib)
         blocks->push_back({pos, clen, xlen, isize, out});
         out += isize;
         pos += clen;
