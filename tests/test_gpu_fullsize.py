@@ -43,11 +43,17 @@ def _posterior_alpha_betas(lc, alt_min, ref_min, n_excluded, n_cells):
     return (a_min, b_min), (a_maj, b_maj), (a_dbl, b_dbl), (np.log(mf), np.log(1.0 - mf), lp_dbl)
 
 
-def _load(engine, L, N, d, seed=4, minority=0.05, doublet=0.0):
+def dm_nnz(g):
+    return g.dims().nnz_used
+
+
+def _load(engine, L, N, d, seed=4, minority=0.05, doublet=0.0, deep=False):
     from cellector_amd import Cellector
     g = Cellector(0)
     g.set_option("engine", engine)
     g.set_option("keep_coo", 0)
+    if deep:  # entry totals 1 + Geometric(0.4): 13 % of the entries outside the regular tables (bench.py's *-deep workloads)
+        g.set_option("synth_continue_pct", 60)
     g.load_synthetic(L, N, d, seed=seed, minority_fraction=minority, doublet_fraction=doublet)
     return g
 
@@ -119,11 +125,16 @@ def test_cfg2_whole_run_matches_oracle(engine, oracle_lib, hip_lib_path):
 
 
 # ---- BASELINE configs[2] and [3]: sampled oracle parity, engine cross-check, properties ----------------------------
-@pytest.mark.parametrize("name,N,L", [("cfg3", 200_000, 100_000), ("cfg4", 1_000_000, 200_000)])
+@pytest.mark.parametrize("name,N,L", [("cfg3", 200_000, 100_000), ("cfg4", 1_000_000, 200_000), ("cfg3-deep", 200_000, 100_000)])
 def test_full_size_sampled_parity_and_properties(name, N, L, oracle_lib, hip_lib_path):
+    """(cfg3-deep: the same shape with deep coverage — the cell side of the totals 5..8 then walks the tier-2 tiles, five chunk
+    groups of them, and the per-entry kernel the compact rest.)"""
     from cellector_amd import ffi, synth
     ob = oracle_lib
-    g = _load(2, L, N, 0.01)
+    deep = name.endswith("-deep")
+    g = _load(2, L, N, 0.01, deep=deep)
+    if deep:
+        assert g.engine_info().nnz_overflow > 0.1 * dm_nnz(g)
     dm = g.dims()
     assert (dm.total_cells, dm.total_loci) == (N, L) and dm.loci_used > 0.9 * L
     lc = g.locus_counts()
@@ -204,7 +215,7 @@ def test_full_size_sampled_parity_and_properties(name, N, L, oracle_lib, hip_lib
     g.close()
 
     # -- the second, independent engine (every entry evaluated by the CSR/CSC kernels) on ALL cells
-    g1 = _load(1, L, N, 0.01)
+    g1 = _load(1, L, N, 0.01, deep=deep)
     s1 = g1.run(5.0, 30)
     assert len(s1) == it + 1 and not s1[-1].any_change
     assert abs(s1[-1].threshold - s.threshold) < 1e-9
