@@ -139,7 +139,9 @@ __global__ __launch_bounds__(64 * TB_PARTS) void k_build_tables(uint64_t L, uint
 // cell pass over the tiles
 // ---------------------------------------------------------------------------------------------------------
 #ifndef TILE_ABL
-#define TILE_ABL 0  // ablation builds of the tile kernel (tools/gpu_ab.sh): 1 no lookups, 2 no entry loads, 3 no table re-staging, 4 conflict-free lookups
+#define TILE_ABL 0  // ablation builds of the tile kernel (tools/gpu_ab.sh; wrong values, timings only): 1 no lookups, 2 rows loaded once, 3 no table
+                    // re-staging, 4 conflict-free lookups, 5 = 1 + 3, 6 conflict-free accumulator updates, 7 no barriers and no re-staging, 8 no
+                    // accumulator access, 9 rows and slice headers loaded once, 10 header loads of the column's first chunk only (cache hits)
 #endif
 // Workgroup barrier that waits for this wave's LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it would wait
 // for the prefetch loads in flight and make them synchronous.
@@ -157,7 +159,11 @@ __global__ __launch_bounds__(64 * TB_PARTS) void k_build_tables(uint64_t L, uint
 #ifndef TILE_PINNED
 #define TILE_PINNED 1
 #endif
+#if TILE_ABL == 7  /* ablation: no chunk barriers (and the table staged once) */
+#define TILE_BARRIER() do { } while (0)
+#else
 #define TILE_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#endif
 
 // Table / entry geometry of a tile set.  geo_reg: the regular entries (totals 1..T_K): 18 doubles per locus, u16 entry =
 // n-1 << 14 | slot << 4 | code.  geo_t2<NMAX>: the tier-2 tiles of a deep-coverage matrix (totals 5..NMAX, tiled_build):
@@ -250,7 +256,8 @@ __global__ __launch_bounds__(T_THREADS, 4) void k_tile_ll(uint32_t nb, uint32_t 
         /* The slices of a tile are sorted by length: wave w takes slice w, 15-w, w+8, 7-w (mod 16) of the      */ \
         /* chunk's tiles, so that all waves carry about the same load between two chunk barriers.               */ \
         const uint32_t rot__ = (wv_s + 8u * (s__ >> 1)) & 15u, sl__ = (s__ & 1u) ? 15u - rot__ : rot__;          \
-        (H) = reinterpret_cast<const uint4 *>(thdr + ((uint64_t)min(b0 + s__, nb - 1) * nj + j__) * T_HDR)[sl__]; \
+        if (TILE_ABL != 9 || first_rows) /* ablation 9: headers loaded in the prologue only; 10: always the column's first chunk's */ \
+        (H) = reinterpret_cast<const uint4 *>(thdr + ((uint64_t)min(b0 + s__, nb - 1) * nj + (TILE_ABL == 10 ? j0 : j__)) * T_HDR)[sl__]; \
     } while (0)
     // this lane's row of the slice with header H.  A row of less than 8 u16 is covered by the first load: the second
     // one then repeats it (never consumed) instead of reading far beyond the row.
@@ -259,8 +266,10 @@ __global__ __launch_bounds__(T_THREADS, 4) void k_tile_ll(uint32_t nb, uint32_t 
         (E).k = (H).z;                                                                                           \
         (E).base = ((uint64_t)(H).y << 32) | (H).x;                                                              \
         const uint16_t *ptr__ = tiles + (E).base + lane * ((H).z + 1u);                                          \
-        (E).lo = *reinterpret_cast<const tile_u4 *>(ptr__);                                                      \
-        (E).hi = *reinterpret_cast<const tile_u4 *>(ptr__ + ((H).z > 7u ? 8u : 0u));                             \
+        if (!(TILE_ABL == 2 || TILE_ABL == 9) || first_rows) { /* ablations 2, 9: rows loaded in the prologue only */ \
+            (E).lo = *reinterpret_cast<const tile_u4 *>(ptr__);                                                  \
+            (E).hi = *reinterpret_cast<const tile_u4 *>(ptr__ + ((H).z > 7u ? 8u : 0u));                         \
+        }                                                                                                        \
     } while (0)
 
     // PFD = prefetch distance in steps = number of pipeline buffers.  With four blocks per column every block of the chunk has
@@ -272,6 +281,7 @@ __global__ __launch_bounds__(T_THREADS, 4) void k_tile_ll(uint32_t nb, uint32_t 
     // The table loads are the OLDEST requests when the chunk loop is entered, like on its back edge, so that the wait
     // for them is a counted vmcnt that leaves the younger row requests in flight (the scheduler must not move them
     // behind the loads below: vmcnt counts in issue order).
+    bool first_rows = true;  // (ablations 2, 9)
     TABLE_PREFETCH(j0);
     __builtin_amdgcn_sched_barrier(0);
     HDR_LOAD(h0, 0);
@@ -287,6 +297,7 @@ __global__ __launch_bounds__(T_THREADS, 4) void k_tile_ll(uint32_t nb, uint32_t 
     if constexpr (PFD >= 3) HDR_LOAD(h2, PFD + 2);
     if constexpr (PFD == 4) HDR_LOAD(h3, PFD + 3);
     uint32_t t = 0;
+    first_rows = false;
 
     // one step: block S of the current chunk, pipeline buffers E / H
     // lookup of entry KK of the row = u16 number KK + 1 = half (KK + 1) & 1 of dword (KK + 1) >> 1.  The slice's K is odd
@@ -353,7 +364,9 @@ __global__ __launch_bounds__(T_THREADS, 4) void k_tile_ll(uint32_t nb, uint32_t 
         HDR_LOAD(H, t + 2 * PFD);                                                                                \
         /* 3. the cell's accumulator is requested first (LDS answers in order: it has landed when the sums are done), */ \
         /*    then this lane's cell of the slice: K lookups for every lane (padding entries hit the zero row) */  \
-        tab_t acc__ = s_acc[(S) * T_BC + (TILE_ABL == 6 ? tid : cell__)];                                        \
+        tab_t acc__;                                                                                             \
+        if constexpr (TILE_ABL == 8) { if constexpr (EXPECTED) acc__ = make_double2(0.0, 0.0); else acc__ = 0.0; }        \
+        else acc__ = s_acc[(S) * T_BC + (TILE_ABL == 6 ? tid : cell__)];                                         \
         double a_ll__ = 0.0, a_el__ = 0.0;                                                                       \
         /* (written out: a loop with an early exit gets re-rolled and then selects its register at run time) */  \
         TILE_RD(v0, 0);                                                                                          \
@@ -378,13 +391,13 @@ __global__ __launch_bounds__(T_THREADS, 4) void k_tile_ll(uint32_t nb, uint32_t 
         /*    are separated by the chunk barriers).  A read and a write: two ds_add_f64 measured 15 % slower.      */ \
         if constexpr (EXPECTED) { acc__.x += a_ll__; acc__.y += a_el__; }                                        \
         else acc__ += a_ll__;                                                                                    \
-        s_acc[(S) * T_BC + (TILE_ABL == 6 ? tid : cell__)] = acc__;                                              \
+        if (TILE_ABL != 8 || a_ll__ == 12345.678) s_acc[(S) * T_BC + (TILE_ABL == 6 ? tid : cell__)] = acc__;   \
         t++;                                                                                                     \
     } while (0)
 
     static_assert(T_SB == 2 || T_SB == 4, "even and odd steps use different pipeline buffers");
     // the table of chunk j into LDS between two barriers, the next chunk's table requested
-#if TILE_ABL == 3 || TILE_ABL == 5  /* ablation: table staged for the first chunk only */
+#if TILE_ABL == 3 || TILE_ABL == 5 || TILE_ABL == 7  /* ablation: table staged for the first chunk only */
 #define TILE_STAGE_IF if (j == j0)
 #define TILE_NEXT_TABLE() do { } while (0)
 #else
