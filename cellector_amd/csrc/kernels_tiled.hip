@@ -215,7 +215,6 @@ __global__ __launch_bounds__(T_THREADS, 4) void k_tile_ll(uint32_t nb, uint32_t 
     const uint32_t g = blockIdx.x % groups;
     const uint32_t j0 = g * cpg, j1 = min(nj, j0 + cpg);
     if (j0 >= j1) return;
-    const uint32_t n_steps = (j1 - j0) * T_SB;
   for (;;) {
     if (tid == 0) s_col = atomicAdd(&work[g], 1u);
     __syncthreads();  // (also: the previous column's partial sums have been read out of s_acc)
@@ -247,17 +246,16 @@ __global__ __launch_bounds__(T_THREADS, 4) void k_tile_ll(uint32_t nb, uint32_t 
     // lo: cell + entries 0..6, hi: entries 7..14; base = first u16 of the slice in `tiles` (wave-uniform, like k: both stay in
     // scalar registers — the row's own address is only needed again by the rare slice with more than T_NE entries per cell)
     struct row_t { tile_u4 lo, hi; uint32_t k; uint64_t base; };
-    // slice header of step T (clamped to the last step; a workgroup at the ragged end re-reads the last block)
+    // slice header of a step (beyond the last chunk: the last chunk's; a workgroup at the ragged end re-reads the last block)
     const uint32_t wv_s = (uint32_t)__builtin_amdgcn_readfirstlane((int)wv);
-#define HDR_LOAD(H, T)                                                                                           \
+#define HDR_LOAD(H, J, S) /* S: a compile-time block number; J: the chunk (clamped by the caller) */           \
     do {                                                                                                         \
-        const uint32_t t__ = min((uint32_t)(T), n_steps - 1);                                                    \
-        const uint32_t j__ = j0 + t__ / T_SB, s__ = t__ % T_SB;                                                  \
         /* The slices of a tile are sorted by length: wave w takes slice w, 15-w, w+8, 7-w (mod 16) of the      */ \
-        /* chunk's tiles, so that all waves carry about the same load between two chunk barriers.               */ \
-        const uint32_t rot__ = (wv_s + 8u * (s__ >> 1)) & 15u, sl__ = (s__ & 1u) ? 15u - rot__ : rot__;          \
+        /* chunk's tiles, so that all waves carry about the same load between two chunk barriers.  (Everything  */ \
+        /* but the chunk is invariant in the chunk loop: a step forms the address with an add and a shift.)     */ \
+        const uint32_t rot__ = (wv_s + 8u * ((uint32_t)(S) >> 1)) & 15u, sl__ = ((S) & 1u) ? 15u - rot__ : rot__; \
         if (TILE_ABL != 9 || first_rows) /* ablation 9: headers loaded in the prologue only; 10: always the column's first chunk's */ \
-        (H) = reinterpret_cast<const uint4 *>(thdr + ((uint64_t)min(b0 + s__, nb - 1) * nj + (TILE_ABL == 10 ? j0 : j__)) * T_HDR)[sl__]; \
+        (H) = reinterpret_cast<const uint4 *>(thdr + ((uint64_t)min(b0 + (uint32_t)(S), nb - 1) * nj + (TILE_ABL == 10 ? j0 : (J))) * T_HDR)[sl__]; \
     } while (0)
     // this lane's row of the slice with header H.  A row of less than 8 u16 is covered by the first load: the second
     // one then repeats it (never consumed) instead of reading far beyond the row.
@@ -265,10 +263,13 @@ __global__ __launch_bounds__(T_THREADS, 4) void k_tile_ll(uint32_t nb, uint32_t 
     do {                                                                                                         \
         (E).k = (H).z;                                                                                           \
         (E).base = ((uint64_t)(H).y << 32) | (H).x;                                                              \
-        const uint16_t *ptr__ = tiles + (E).base + lane * ((H).z + 1u);                                          \
+        /* (a wave-uniform 64-bit base in scalar registers plus a 32-bit byte offset per lane: the loads take the  */ \
+        /*  scalar-base form, and the address costs one multiply instead of 64-bit vector arithmetic)               */ \
+        const char *sb__ = reinterpret_cast<const char *>(tiles + (E).base);                                     \
+        const uint32_t off__ = lane * (((H).z + 1u) * 2u);                                                       \
         if (!(TILE_ABL == 2 || TILE_ABL == 9) || first_rows) { /* ablations 2, 9: rows loaded in the prologue only */ \
-            (E).lo = *reinterpret_cast<const tile_u4 *>(ptr__);                                                  \
-            (E).hi = *reinterpret_cast<const tile_u4 *>(ptr__ + ((H).z > 7u ? 8u : 0u));                         \
+            (E).lo = *reinterpret_cast<const tile_u4 *>(sb__ + off__);                                           \
+            (E).hi = *reinterpret_cast<const tile_u4 *>(sb__ + ((H).z > 7u ? 16u : 0u) + off__);                 \
         }                                                                                                        \
     } while (0)
 
@@ -284,19 +285,20 @@ __global__ __launch_bounds__(T_THREADS, 4) void k_tile_ll(uint32_t nb, uint32_t 
     bool first_rows = true;  // (ablations 2, 9)
     TABLE_PREFETCH(j0);
     __builtin_amdgcn_sched_barrier(0);
-    HDR_LOAD(h0, 0);
-    HDR_LOAD(h1, 1);
-    if constexpr (PFD >= 3) HDR_LOAD(h2, 2);
-    if constexpr (PFD == 4) HDR_LOAD(h3, 3);
+#define HDR_STEP(H, T) HDR_LOAD(H, min(j0 + (uint32_t)(T) / T_SB, j1 - 1), (uint32_t)(T) % T_SB)  /* header of step T of the column */
+    HDR_STEP(h0, 0);
+    HDR_STEP(h1, 1);
+    if constexpr (PFD >= 3) HDR_STEP(h2, 2);
+    if constexpr (PFD == 4) HDR_STEP(h3, 3);
     ROW_LOAD(e0, h0);
     ROW_LOAD(e1, h1);
     if constexpr (PFD >= 3) ROW_LOAD(e2, h2);
     if constexpr (PFD == 4) ROW_LOAD(e3, h3);
-    HDR_LOAD(h0, PFD);
-    HDR_LOAD(h1, PFD + 1);
-    if constexpr (PFD >= 3) HDR_LOAD(h2, PFD + 2);
-    if constexpr (PFD == 4) HDR_LOAD(h3, PFD + 3);
-    uint32_t t = 0;
+    HDR_STEP(h0, PFD);
+    HDR_STEP(h1, PFD + 1);
+    if constexpr (PFD >= 3) HDR_STEP(h2, PFD + 2);
+    if constexpr (PFD == 4) HDR_STEP(h3, PFD + 3);
+#undef HDR_STEP
     first_rows = false;
 
     // one step: block S of the current chunk, pipeline buffers E / H
@@ -361,7 +363,7 @@ __global__ __launch_bounds__(T_THREADS, 4) void k_tile_ll(uint32_t nb, uint32_t 
         const uint32_t cell__ = w__[0] & 0xffffu;                                                                \
         /* 2. issue the next requests: rows of step t+PFD (their header is here), header of step t+2 PFD */      \
         ROW_LOAD(E, H);                                                                                          \
-        HDR_LOAD(H, t + 2 * PFD);                                                                                \
+        HDR_LOAD(H, min(j + ((S) + 2 * PFD) / T_SB, j1 - 1), ((S) + 2 * PFD) % T_SB);                            \
         /* 3. the cell's accumulator is requested first (LDS answers in order: it has landed when the sums are done), */ \
         /*    then this lane's cell of the slice: K lookups for every lane (padding entries hit the zero row) */  \
         tab_t acc__;                                                                                             \
@@ -392,7 +394,6 @@ __global__ __launch_bounds__(T_THREADS, 4) void k_tile_ll(uint32_t nb, uint32_t 
         if constexpr (EXPECTED) { acc__.x += a_ll__; acc__.y += a_el__; }                                        \
         else acc__ += a_ll__;                                                                                    \
         if (TILE_ABL != 8 || a_ll__ == 12345.678) s_acc[(S) * T_BC + (TILE_ABL == 6 ? tid : cell__)] = acc__;   \
-        t++;                                                                                                     \
     } while (0)
 
     static_assert(T_SB == 2 || T_SB == 4, "even and odd steps use different pipeline buffers");
