@@ -39,7 +39,7 @@ for w in ("cfg4", "cfg3"):
         vals, on = {}, False
         for ln in open(sq_log):
             if not ln.startswith(" "):
-                on = ln.startswith("void k_tile_ll<true, 4>")
+                on = ln.startswith("void k_tile_ll<true, 4")
             elif on and len(ln.split()) >= 2:
                 vals[ln.split()[0]] = float(ln.split()[1])
         if {"SQ_BUSY_CYCLES", "SQ_LDS_IDX_ACTIVE", "SQ_LDS_BANK_CONFLICT", "SQ_WAIT_INST_ANY", "SQ_WAVE_CYCLES"} <= set(vals):
