@@ -266,7 +266,7 @@ __global__ __launch_bounds__(T_THREADS, 4) void k_tile_ll(uint32_t nb, uint32_t 
         /* (a wave-uniform 64-bit base in scalar registers plus a 32-bit byte offset per lane: the loads take the  */ \
         /*  scalar-base form, and the address costs one multiply instead of 64-bit vector arithmetic)               */ \
         const char *sb__ = reinterpret_cast<const char *>(tiles + (E).base);                                     \
-        const uint32_t off__ = lane * (((H).z + 1u) * 2u);                                                       \
+        const uint32_t off__ = __umul24(lane, ((H).z + 1u) * 2u); /* (full-rate 24-bit multiply) */                     \
         if (!(TILE_ABL == 2 || TILE_ABL == 9) || first_rows) { /* ablations 2, 9: rows loaded in the prologue only */ \
             (E).lo = *reinterpret_cast<const tile_u4 *>(sb__ + off__);                                           \
             (E).hi = *reinterpret_cast<const tile_u4 *>(sb__ + ((H).z > 7u ? 16u : 0u) + off__);                 \
