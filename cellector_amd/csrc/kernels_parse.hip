@@ -339,10 +339,14 @@ bool load_bytes(const char *path, FileBytes *fb)
                     std::vector<BgzfBlock> blocks;
                     size_t total = 0;
                     bool done = false;
-                    if (bgzf_index((const uint8_t *)m, (size_t)st.st_size, &blocks, &total)) {
-                        fb->owned.resize(total ? total : 1);
-                        done = bgzf_inflate((const uint8_t *)m, blocks, fb->owned.data());
-                        if (done) { fb->data = fb->owned.data(); fb->size = total; }
+                    try {
+                        if (bgzf_index((const uint8_t *)m, (size_t)st.st_size, &blocks, &total)) {
+                            fb->owned.resize(total ? total : 1);
+                            done = bgzf_inflate((const uint8_t *)m, blocks, fb->owned.data());
+                            if (done) { fb->data = fb->owned.data(); fb->size = total; }
+                        }
+                    } catch (const std::exception &) {  // (no room for the index or the text: the serial reader decides)
+                        done = false;
                     }
                     munmap(m, (size_t)st.st_size);
                     if (done) { close(fd); return true; }
