@@ -261,13 +261,13 @@ __global__ __launch_bounds__(T_THREADS, 4) void k_tile_ll(uint32_t nb, uint32_t 
     // one then repeats it (never consumed) instead of reading far beyond the row.
 #define ROW_LOAD(E, H)                                                                                           \
     do {                                                                                                         \
-        (E).k = (H).z;                                                                                           \
+        (E).k = (SKIP_EMPTY && (H).w) ? 0u : (H).z; /* 0: a slice without entries (tier-2 tiles): the step skips it */ \
         (E).base = ((uint64_t)(H).y << 32) | (H).x;                                                              \
         /* (a wave-uniform 64-bit base in scalar registers plus a 32-bit byte offset per lane: the loads take the  */ \
         /*  scalar-base form, and the address costs one multiply instead of 64-bit vector arithmetic)               */ \
         const char *sb__ = reinterpret_cast<const char *>(tiles + (E).base);                                     \
         const uint32_t off__ = __umul24(lane, ((H).z + 1u) * 2u); /* (full-rate 24-bit multiply) */                     \
-        if (!(TILE_ABL == 2 || TILE_ABL == 9) || first_rows) { /* ablations 2, 9: rows loaded in the prologue only */ \
+        if ((!(TILE_ABL == 2 || TILE_ABL == 9) || first_rows) && !(SKIP_EMPTY && (H).w)) { /* ablations 2, 9: rows loaded in the prologue only */ \
             (E).lo = *reinterpret_cast<const tile_u4 *>(sb__ + off__);                                           \
             (E).hi = *reinterpret_cast<const tile_u4 *>(sb__ + ((H).z > 7u ? 16u : 0u) + off__);                 \
         }                                                                                                        \
@@ -275,6 +275,12 @@ __global__ __launch_bounds__(T_THREADS, 4) void k_tile_ll(uint32_t nb, uint32_t 
 
     // PFD = prefetch distance in steps = number of pipeline buffers.  With four blocks per column every block of the chunk has
     // a buffer of its own and the rows are requested a whole chunk ahead.
+    // The tier-2 tiles of a deep matrix hold 0.4 entries per row: ten of a tile's sixteen slices (sorted by length) have none, and a
+    // wave whose slice is marked so in its header skips the step — no row loads, no lookups, no accumulator update: that kernel alone
+    // 1.90 -> 1.46 ms at 10^6 cells x 200k loci deep.  (It costs 6 VGPRs — 106: the per-entry kernels of the side stream, 88, then
+    // find no room beside it and wait for it; the iteration still gains, 5.4 -> 5.0 ms.  Sharing ONE all-padding slice between the
+    // empty slices instead, with the kernel unchanged, would update the same accumulators from several waves: not an option.)
+    constexpr bool SKIP_EMPTY = G::NLO != 1;
     constexpr uint32_t PFD = T_SB == 4 ? (uint32_t)(G::NLO == 1 ? TILE_PFD : TILE_PFD_T2) : 2u;
     static_assert(PFD >= 2 && PFD <= 4, "row buffers");
     uint4 h0, h1, h2, h3;   // at the top of step t (t % PFD == 0): slice headers of steps t+PFD (h0), t+PFD+1 (h1), ...
@@ -366,6 +372,7 @@ __global__ __launch_bounds__(T_THREADS, 4) void k_tile_ll(uint32_t nb, uint32_t 
         HDR_LOAD(H, min(j + ((S) + 2 * PFD) / T_SB, j1 - 1), ((S) + 2 * PFD) % T_SB);                            \
         /* 3. the cell's accumulator is requested first (LDS answers in order: it has landed when the sums are done), */ \
         /*    then this lane's cell of the slice: K lookups for every lane (padding entries hit the zero row) */  \
+        if (!(SKIP_EMPTY && K__ == 0u)) {                                                                        \
         tab_t acc__;                                                                                             \
         if constexpr (TILE_ABL == 8) { if constexpr (EXPECTED) acc__ = make_double2(0.0, 0.0); else acc__ = 0.0; }        \
         else acc__ = s_acc[(S) * T_BC + (TILE_ABL == 6 ? tid : cell__)];                                         \
@@ -394,6 +401,7 @@ __global__ __launch_bounds__(T_THREADS, 4) void k_tile_ll(uint32_t nb, uint32_t 
         if constexpr (EXPECTED) { acc__.x += a_ll__; acc__.y += a_el__; }                                        \
         else acc__ += a_ll__;                                                                                    \
         if (TILE_ABL != 8 || a_ll__ == 12345.678) s_acc[(S) * T_BC + (TILE_ABL == 6 ? tid : cell__)] = acc__;   \
+        }                                                                                                        \
     } while (0)
 
     static_assert(T_SB == 2 || T_SB == 4, "even and odd steps use different pipeline buffers");
@@ -1101,43 +1109,46 @@ __global__ __launch_bounds__(256) void k_ovf_cell_listed(uint64_t n_list, const 
     if (EXPECTED) o_ell[row] += e;
 }
 
-// Totals above OV_NE (tier 1: a few entries in 10^4 even with deep coverage) take the generic arithmetic — chunked products,
-// and for the expected term the reference's log-space fold over all n + 1 pmfs: O(n^2) for one thread, and a wave waits for its
-// longest total (0.40 ms at 200k x 100k deep: more than the kernel of all other overflow entries).  Here 16 lanes share a listed
-// entry: lane j folds the terms k = j, j + 16, ... left to right, the 16 partial results meet in a fixed-shape butterfly
-// (logsumexp is commutative: every lane ends with the same bits; the association differs from the reference's single left fold
-// by rounding only).  The values go to two small arrays; k_ovf_listed_add walks each row's run and adds them in list order.
-template <bool EXPECTED>
-__global__ __launch_bounds__(256) void k_ovf_listed_values(uint64_t n_list, const uint64_t *__restrict__ ents,
-                                                           const double2 *__restrict__ ab, const double *__restrict__ lf,
-                                                           double *__restrict__ v_lp, double *__restrict__ v_e)
+// ln sum_k pmf(k)^2 (stats.rs:8-22) for any n, in O(n): the pmfs relative to the one next to the mode, k* = round(n alpha / (alpha +
+// beta)), by the ratio recurrence upwards and downwards from there (terms far from the mode underflow to zero harmlessly, none
+// overflows: pmf(k) / pmf(k*) stays near or below one), then ln(sum) + 2 ln pmf(k*).  The reference folds all n + 1 log-pmfs in
+// log space (O(n^2) the way a thread has to evaluate them); this differs from it by rounding only — engine 1 keeps the fold, and
+// every parity test runs both engines.
+__device__ __noinline__ double ov_expected_mode(const double *lf, double alpha, double beta, uint32_t n)
 {
-    const uint32_t j = threadIdx.x % LF_LANES;
-    const uint64_t idx = ((uint64_t)blockIdx.x * 256 + threadIdx.x) / LF_LANES;
-    const bool in = idx < n_list;
-    const uint64_t i = in ? idx : n_list - 1;  // whole waves stay in the butterfly
+    const double fn = (double)n;
+    uint32_t ks = (uint32_t)(fn * alpha * ov_rcp(alpha + beta) + 0.5);
+    if (ks > n) ks = n;
+    double s = 1.0, t = 1.0;
+    for (uint32_t k = ks; k < n; ++k) {  // pmf(k+1) / pmf(k) = (n-k)(alpha+k) / ((k+1)(beta+n-k-1))
+        t *= ((double)(n - k) * (alpha + (double)k)) * ov_rcp((double)(k + 1) * (beta + (double)(n - k - 1)));
+        s += t * t;
+    }
+    t = 1.0;
+    for (uint32_t k = ks; k > 0; --k) {  // pmf(k-1) / pmf(k) = k (beta+n-k) / ((n-k+1)(alpha+k-1))
+        t *= ((double)k * (beta + (double)(n - k))) * ov_rcp((double)(n - k + 1) * (alpha + (double)(k - 1)));
+        s += t * t;
+    }
+    return log(s) + 2.0 * dm_log_bb_pmf(lf, alpha, beta, ks, n - ks);
+}
+
+// Totals above OV_NE (tier 1: a few entries in 10^4 even with deep coverage): chunked products for the log-pmf, the mode-anchored
+// recurrence above for the expected term — a thread per listed entry, at most 64 VGPRs so that a wave fits beside the tile kernel's
+// four per SIMD.  (Until round 3 the expected term was the reference's log-space fold, 16 lanes per entry.)  The values go to two
+// small arrays; k_ovf_listed_add walks each row's run and adds them in list order.
+template <bool EXPECTED>
+__global__ __launch_bounds__(256, 8) void k_ovf_listed_values(uint64_t n_list, const uint64_t *__restrict__ ents,
+                                                              const double2 *__restrict__ ab, const double *__restrict__ lf,
+                                                              double *__restrict__ v_lp, double *__restrict__ v_e)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_list) return;
     const uint64_t en = ents[i];
     const uint32_t l = ENT_IDX(en), a = ENT_ALT(en), r = ENT_REF(en), n = a + r;
     const double2 p = ab[l];
     const bool live = p.x >= 0.0;  // else a masked locus: no PMFData (main.rs:556)
-    double lp = 0.0, e = 0.0;
-    if (live && j == 0) lp = dm_log_bb_pmf(lf, p.x, p.y, a, r);
-    if (EXPECTED && live) {
-        // (n > OV_NE >= LF_LANES: every lane has at least the term k = j)
-        e = 2.0 * dm_log_bb_pmf(lf, p.x, p.y, j, n - j);
-        for (uint32_t k = j + LF_LANES; k <= n; k += LF_LANES) e = dm_logsumexp(e, 2.0 * dm_log_bb_pmf(lf, p.x, p.y, k, n - k));
-    }
-    if (EXPECTED) {
-#pragma unroll
-        for (int m = LF_LANES / 2; m > 0; m >>= 1) {
-            const double o = __shfl_xor(e, m, LF_LANES);
-            if (live) e = dm_logsumexp(e, o);
-        }
-    }
-    if (in && j == 0) {
-        v_lp[i] = lp;
-        if (EXPECTED) v_e[i] = live ? e : 0.0;
-    }
+    v_lp[i] = live ? dm_log_bb_pmf(lf, p.x, p.y, a, r) : 0.0;
+    if (EXPECTED) v_e[i] = live ? ov_expected_mode(lf, p.x, p.y, n) : 0.0;
 }
 template <bool EXPECTED>
 __global__ __launch_bounds__(256) void k_ovf_listed_add(uint64_t n_list, const uint32_t *__restrict__ rows, const double *__restrict__ v_lp,
@@ -1871,7 +1882,7 @@ __global__ __launch_bounds__(T_BC) void k_tile_build(uint64_t nloc, uint32_t nj,
         hd[0] = (uint32_t)first;
         hd[1] = (uint32_t)(first >> 32);
         hd[2] = s_kmax[cl] | 1u;  // K: padded entries per cell of the slice (odd: a row is K + 1 u16)
-        hd[3] = 0;
+        hd[3] = s_kmax[cl] == 0u;  // no row of the slice has an entry (the nearly empty tier-2 tiles of a deep matrix: most slices)
     }
     const uint32_t K = s_kmax[dw] | 1u;
     uint16_t *dst = tiles + tbase + s_sbase[dw] + dl * (K + 1u);  // this cell's row
@@ -2103,7 +2114,7 @@ __global__ __launch_bounds__(T_BC, 8) void k_tile_build2(uint64_t nloc, uint32_t
                     hd[0] = (uint32_t)first;
                     hd[1] = (uint32_t)(first >> 32);
                     hd[2] = s_kmax[cl] | 1u;
-                    hd[3] = 0;
+                    hd[3] = s_kmax[cl] == 0u;
                 }
                 const uint32_t K = s_kmax[dw] | 1u;
                 const bool staged = total <= (uint32_t)TB_STAGE;  // (uniform)
@@ -2686,7 +2697,7 @@ static void launch_overflow_cell(cellector_ctx *c, hipStream_t st, const double2
                 hipLaunchKernelGGL((k_ovf_cell_listed<E, false>), dim3(gcap(c->ovf_n_tier[0], 256, 0x7fffffffu)), dim3(256), 0, st, \
                                    c->ovf_n_tier[0], c->ovf_tier_row[0], c->ovf_tier_ent[0], ab, c->lf, c->ovf_tab, o_ll, o_ell); \
             if (c->ovf_n_tier[1]) {                                                                                        \
-                hipLaunchKernelGGL(k_ovf_listed_values<E>, dim3(gcap(c->ovf_n_tier[1] * LF_LANES, 256, 0x7fffffffu)), dim3(256), 0, st, \
+                hipLaunchKernelGGL(k_ovf_listed_values<E>, dim3(gcap(c->ovf_n_tier[1], 256, 0x7fffffffu)), dim3(256), 0, st, \
                                    c->ovf_n_tier[1], c->ovf_tier_ent[1], ab, c->lf, c->ovf_tier_val, c->ovf_tier_val + c->ovf_n_tier[1]); \
                 hipLaunchKernelGGL(k_ovf_listed_add<E>, dim3(gcap(c->ovf_n_tier[1], 256, 0x7fffffffu)), dim3(256), 0, st, c->ovf_n_tier[1], \
                                    c->ovf_tier_row[1], c->ovf_tier_val, c->ovf_tier_val + c->ovf_n_tier[1], o_ll, o_ell);  \
@@ -2718,7 +2729,7 @@ static void launch_overflow_cell(cellector_ctx *c, hipStream_t st, const double2
             hipLaunchKernelGGL((k_ovf_cell_listed<true, false>), dim3(gcap(c->ovf_n_tier[0], 256, 0x7fffffffu)), dim3(256), 0, st,
                                c->ovf_n_tier[0], c->ovf_tier_row[0], c->ovf_tier_ent[0], ab, c->lf, c->ovf_tab, o_ll, o_ell);
         if (c->ovf_n_tier[1]) {
-            hipLaunchKernelGGL(k_ovf_listed_values<true>, dim3(gcap(c->ovf_n_tier[1] * LF_LANES, 256, 0x7fffffffu)), dim3(256), 0, st,
+            hipLaunchKernelGGL(k_ovf_listed_values<true>, dim3(gcap(c->ovf_n_tier[1], 256, 0x7fffffffu)), dim3(256), 0, st,
                                c->ovf_n_tier[1], c->ovf_tier_ent[1], ab, c->lf, c->ovf_tier_val, c->ovf_tier_val + c->ovf_n_tier[1]);
             hipLaunchKernelGGL(k_ovf_listed_add<true>, dim3(gcap(c->ovf_n_tier[1], 256, 0x7fffffffu)), dim3(256), 0, st, c->ovf_n_tier[1],
                                c->ovf_tier_row[1], c->ovf_tier_val, c->ovf_tier_val + c->ovf_n_tier[1], o_ll, o_ell);
@@ -2737,7 +2748,7 @@ static void launch_overflow_cell(cellector_ctx *c, hipStream_t st, const double2
             hipLaunchKernelGGL((k_ovf_cell_listed<false, false>), dim3(gcap(c->ovf_n_tier[0], 256, 0x7fffffffu)), dim3(256), 0, st,
                                c->ovf_n_tier[0], c->ovf_tier_row[0], c->ovf_tier_ent[0], ab, c->lf, c->ovf_tab, o_ll, o_ell);
         if (c->ovf_n_tier[1]) {
-            hipLaunchKernelGGL(k_ovf_listed_values<false>, dim3(gcap(c->ovf_n_tier[1] * LF_LANES, 256, 0x7fffffffu)), dim3(256), 0, st,
+            hipLaunchKernelGGL(k_ovf_listed_values<false>, dim3(gcap(c->ovf_n_tier[1], 256, 0x7fffffffu)), dim3(256), 0, st,
                                c->ovf_n_tier[1], c->ovf_tier_ent[1], ab, c->lf, c->ovf_tier_val, c->ovf_tier_val + c->ovf_n_tier[1]);
             hipLaunchKernelGGL(k_ovf_listed_add<false>, dim3(gcap(c->ovf_n_tier[1], 256, 0x7fffffffu)), dim3(256), 0, st, c->ovf_n_tier[1],
                                c->ovf_tier_row[1], c->ovf_tier_val, c->ovf_tier_val + c->ovf_n_tier[1], o_ll, o_ell);
