@@ -89,7 +89,8 @@ def roofline(args, kernel, launch_ms, units, b_alg, achieved, traffic, traffic_s
                       "frac": lds_frac,  # conflict-free share of the LDS pipe's time that the lookups alone need
                       "sq_counters": sq,  # measured: LDS pipe busy / bank-conflict share / wait share (profiles/*_sq_tile.csv)
                       "note": "random 8-byte lookups: the measured LDS-busy share is ~2.6x the conflict-free figure (bank "
-                              "conflicts); the rest of the time the waves wait for tile rows (HBM latency at 4 waves/SIMD)"}
+                              "conflicts); ablations of the kernel alone (DESIGN 3.3b): 1.0 ms without lookups and table re-staging (a wave's own "
+                              "instruction stream and row loads, 4 waves/SIMD), + 0.22 re-staging, + 0.27 lookups of which 0.11 conflicts"}
         if out["frac"] > 1.0:
             out["frac_note"] = "above 1 because the tiled layout moves 1/3 of the algorithmic bytes; see hbm_frac_measured / lds"
     else:
