@@ -382,6 +382,7 @@ cellector_status cellector_set_option(cellector_ctx *c, const char *key, int64_t
     }
     else if (!strcmp(key, "keep_coo")) c->keep_coo = v != 0;
     else if (!strcmp(key, "bank_order")) c->bank_order = v != 0;
+    else if (!strcmp(key, "fuse_filter")) c->fuse_filter = v != 0;
     else if (!strcmp(key, "synth_continue_pct")) {
         if (v < 0 || v > 90) return ctx_fail(c, CELLECTOR_EINVAL, "synth_continue_pct must be within 0..90");
         c->synth_continue_pct = (int)v;
@@ -902,7 +903,8 @@ cellector_status cellector_em_finish(cellector_ctx *c, cellector_iter_summary *o
     SETDEV(c);
     // exchange point 3: per-locus minority tallies, contribution sums and the change counters
     if (comm_active(c->comm)) CHK((cellector_status)comm_allreduce_sum(c, c->x_locus, (uint64_t)LB_PLANES * c->L + LC_COUNTERS));
-    CHK(launch_locus_filter(c));
+    if (c->filter_fused) c->filter_fused = false;  // (engine 2, unsharded: k_locus_finalize applied the filter)
+    else CHK(launch_locus_filter(c));
     CHK(launch_iter_summary(c));
     // the next iteration's first kernel is queued behind the summary: it runs while the host waits for the summary, wakes
     // up and decides (should the loop end here, the tables it built are simply never used)

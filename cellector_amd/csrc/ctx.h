@@ -69,6 +69,8 @@ struct cellector_ctx {
     bool compute_expected = true;
     bool ref_arith = false;  // option ref_arith (engine 1): evaluate stats.rs:41-53 with ln_gamma differences, the reference's own rounding
     int64_t parse_window_opt = 0;  // option parse_window: 0 = whole file below 1 GB, 256 MB windows above; else the window in bytes
+    bool fuse_filter = true;   // option "fuse_filter": an unsharded ctx applies the -80 locus filter inside k_locus_finalize (A/B)
+    bool filter_fused = false;  // this iteration's locus pass did so (em_finish then launches no k_locus_filter)
     bool bank_order = true;  // option "bank_order": the tile builder orders every row's entries against LDS bank conflicts (tile_bank_order)
     int tile_groups_opt = 0;  // option tile_groups: 0 = chosen per matrix (tiled_setup), else forced (multiple of 8)
     // option sharded_select: a ctx with a communicator exchanges digit histograms (1) or all-gathers NORM (0); -1 = by the

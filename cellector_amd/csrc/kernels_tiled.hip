@@ -1580,7 +1580,9 @@ __global__ __launch_bounds__(256) void k_locus_finalize(uint64_t L, int locus_mo
                                                         const double2 *__restrict__ ab, double *__restrict__ out,
                                                         uint32_t *__restrict__ cnt2 /*null: no tier 2*/,
                                                         const uint32_t *__restrict__ hist_all2, const uint32_t *__restrict__ pmask2,
-                                                        const double *__restrict__ tab2)
+                                                        const double *__restrict__ tab2,
+                                                        uint8_t *__restrict__ mask_next /*null: the locus filter is a kernel of its own*/,
+                                                        uint32_t *__restrict__ n_filtered)
 {
     // the minority-driven form left n_sub planes of u16 counts, the streamed form one plane of u32 counts
     const bool by_min = locus_by_minority(locus_mode, *n_min_p, nloc, n_sub);
@@ -1686,6 +1688,18 @@ __global__ __launch_bounds__(256) void k_locus_finalize(uint64_t L, int locus_mo
         out[LB_CELLS_MIN * L + l] = (double)nmin;
         out[LB_ALT_MIN * L + l] = (double)amin;
         out[LB_REF_MIN * L + l] = (double)rmin;
+        // An unsharded ctx has the locus' final sums right here: the -80 filter of locus_filter_and_output_locus_data
+        // (main.rs:428-451; k_locus_filter's arithmetic on the values just written) without a launch of its own.
+        if (mask_next) {
+            const double fn = (double)nmin;
+            const double per_cell = fn != 0.0 ? cmin / fn : 0.0;
+            uint8_t m = mask[l];
+            if (per_cell < -80.0) {
+                m = 0;
+                atomicAdd(n_filtered, 1u);
+            }
+            mask_next[l] = m;
+        }
     }
 }
 
@@ -3024,7 +3038,10 @@ cellector_status tiled_locus_pass(cellector_ctx *c)
     hipLaunchKernelGGL(k_locus_finalize<INL>, dim3(gcap(c->L * LF_LANES, 256, 0x7fffffffu)), dim3(256), 0, c->stream, c->L, c->locus_mode, \
                        c->nloc, c->lr_sub, c->d_counters + DC_N_MIN, c->hist_min, c->flag_bits, c->hist_all, c->tab_em,            \
                        (uint32_t)c->tab_em_stride, c->mask, w_ptr, w_ent, w_lp, c->ovf_tab, c->lf, c->ab, c->x_locus,              \
-                       c->t2 ? c->cnt2 : (uint32_t *)nullptr, c->hist_all2, c->t2_pmask, c->tab2)
+                       c->t2 ? c->cnt2 : (uint32_t *)nullptr, c->hist_all2, c->t2_pmask, c->tab2,                                    \
+                       c->filter_fused ? c->mask_next : (uint8_t *)nullptr, c->d_counters)
+    // (a ctx that holds all cells and has no communicator: nothing is exchanged between the finalize and the filter)
+    c->filter_fused = !comm_active(c->comm) && c->nloc == c->total_cells && c->fuse_filter;
     if (c->ovf_deep) LAUNCH_LF(true); else LAUNCH_LF(false);
 #undef LAUNCH_LF
     timer_end(c, CELLECTOR_K_LOCUS_STATS);
