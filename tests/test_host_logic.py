@@ -146,3 +146,26 @@ def test_cfg1_oracle_regression():
     assert got["posterior_sum"] == pytest.approx(want["posterior_sum"], abs=1e-9)
     cls = synth.cell_classes(1000, seed=4)
     assert sorted(np.nonzero(cls == 1)[0].tolist()) == want["excluded_cells"]  # finds exactly the planted minority
+
+
+def test_bgzf_writer_makes_valid_multi_member_gzip():
+    """synth.bgzf_compress (the test inputs of the block-parallel .gz reader): every member carries the 'BC' size field and the
+    whole file inflates to the text with any multi-member gzip reader (the reference uses flate2's MultiGzDecoder)."""
+    import gzip
+    import struct
+
+    from cellector_amd import synth
+    text = b"".join(b"%d %d %d\n" % (i, i % 97 + 1, i % 5) for i in range(1, 60000))
+    blob = synth.bgzf_compress(text, block=5000)
+    assert gzip.decompress(blob) == text
+    pos, blocks, total = 0, 0, 0
+    while pos < len(blob):
+        assert blob[pos:pos + 4] == b"\x1f\x8b\x08\x04"
+        xlen, = struct.unpack_from("<H", blob, pos + 10)
+        assert blob[pos + 12:pos + 14] == b"BC" and xlen == 6
+        bsize, = struct.unpack_from("<H", blob, pos + 16)
+        isize, = struct.unpack_from("<I", blob, pos + bsize + 1 - 4)
+        total += isize
+        pos += bsize + 1
+        blocks += 1
+    assert pos == len(blob) and total == len(text) and blocks == (len(text) + 4999) // 5000 + 1  # (+ the empty end-of-file member)
