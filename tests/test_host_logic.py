@@ -55,6 +55,18 @@ def test_mtx_writer_roundtrip(tmp_path, oracle_lib):
         assert np.array_equal(o1.row_ptr(), o2.row_ptr())
         for x, y in zip(o1.entries(), o2.entries()):
             assert np.array_equal(x, y)
+    # the same pair block-compressed (bgzip layout, several members): a multi-member gzip like any other to the oracle's zlib reader
+    # (load_data.rs:246: MultiGzDecoder); the product inflates such files block-parallel (tests/test_gpu_parity.py)
+    a, r = synth.write_mtx_pair(str(tmp_path / "plain2"), 120, 90, lo, ce, al, re, header_nnz=0)
+    paths = []
+    for src in (a, r):
+        dst = src + ".gz"
+        open(dst, "wb").write(synth.bgzf_compress(open(src, "rb").read(), block=700))
+        paths.append(dst)
+    o3 = oracle_lib.Oracle.from_mtx(paths[0], paths[1], 2, 2)
+    assert o3.nnz == o2.nnz and np.array_equal(o3.row_ptr(), o2.row_ptr())
+    for x, y in zip(o3.entries(), o2.entries()):
+        assert np.array_equal(x, y)
 
 
 def test_oracle_mtx_text_contract(tmp_path, oracle_lib):
